@@ -1,0 +1,201 @@
+/*
+ * qsv.h -- C ABI of libqsv.so, the MI355X (gfx950) fp64 statevector engine that replaces
+ * the Qiskit-Aer call of the reference's hot path:
+ *
+ *     simulator = Aer.get_backend('qasm_simulator')            /root/reference/run_experiment.py:54
+ *     result    = simulator.run(T, shots=SHOTS).result()       /root/reference/run_experiment.py:56
+ *     counts    = result.get_counts()                          /root/reference/run_experiment.py:57
+ *
+ * The reference's "FFI" for this path is the Python -> Aer C++ extension call hidden inside
+ * run(); this header is what a ctypes (or cgo / JNI) binding of that call binds instead.
+ * Every entry point names the reference gate / step it executes (file:line into
+ * /root/reference).  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *  - amplitude vector: 2^n_qubits complex128, interleaved (re, im); qubit q <-> bit q of the
+ *    basis index (Qiskit little-endian).  Qubit numbers here are PHYSICAL positions; the
+ *    Python host keeps the logical->physical layout map.
+ *  - sharding: P = 2^g shards by the g highest physical qubits; shard s holds indices
+ *    [s << L, (s+1) << L), L = n_qubits - g.  Qubits >= L are "shard bits".
+ *  - every pointer argument is a caller-owned host buffer, read or filled synchronously;
+ *    nothing is retained after return.  No callbacks.
+ *  - return 0 on success; <0 on error (QSV_E_*); text via qsv_last_error() (thread local).
+ *  - a handle is not thread-safe; distinct handles may be used from distinct threads.
+ *  - gate calls are asynchronous on the device stream(s); results are synchronised by
+ *    qsv_sync / qsv_probabilities / qsv_sample / qsv_get_amplitudes / qsv_get_stats.
+ */
+#ifndef QSV_H
+#define QSV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qsv_handle qsv_handle;
+
+#define QSV_OK             0
+#define QSV_E_BADARG      -1
+#define QSV_E_NOMEM       -2
+#define QSV_E_HIP         -3
+#define QSV_E_RCCL        -4
+#define QSV_E_UNSUPPORTED -5
+
+#define QSV_MAX_CTRL      16   /* controls of one gate / qubits of one diagonal        */
+#define QSV_MAX_KQ         5   /* dense k-qubit unitary                                */
+#define QSV_UNIQUE_ID_BYTES 128
+
+/* kernel kinds, index into qsv_stats.per_kind[] */
+enum {
+  QSV_K_INIT = 0, QSV_K_1Q, QSV_K_X, QSV_K_DIAG, QSV_K_MCPHASE, QSV_K_MUX, QSV_K_KQ,
+  QSV_K_PROB, QSV_K_SWAP, QSV_K_EXCHANGE, QSV_K_MULTI, QSV_K_COUNT
+};
+
+typedef struct {
+  uint64_t launches;          /* kernel launches of this kind                              */
+  double   algorithmic_bytes; /* SURVEY.md 8(d) byte model, summed                         */
+  double   device_ms;         /* HIP-event time on the launch stream (profiling on only)   */
+} qsv_kind_stats;
+
+typedef struct {
+  qsv_kind_stats per_kind[QSV_K_COUNT];
+  uint64_t exchanges;         /* shard-bit exchanges performed                              */
+  double   exchange_bytes;    /* bytes sent over the fabric by this process                 */
+} qsv_stats;
+
+/* ---- life cycle -------------------------------------------------------------------- */
+
+/* number of visible HIP devices (<0 on error) */
+int qsv_device_count(void);
+
+/* One process drives n_devices shards (n_devices a power of two).  device_ids[i] is the HIP
+ * device of shard i; repeating an id places several ("virtual") shards on one GPU.
+ * Replaces: the state allocation inside Aer's run() (run_experiment.py:56). */
+int qsv_create(int n_qubits, int n_devices, const int* device_ids, qsv_handle** out);
+
+/* One process per GPU (torchrun-style launch): this process owns shard `rank` of
+ * `world_size` (a power of two) on HIP device device_id.  Exchanges go over RCCL once
+ * qsv_comm_init has been called on every rank. */
+int qsv_create_rank(int n_qubits, int world_size, int rank, int device_id, qsv_handle** out);
+
+/* RCCL bootstrap for qsv_create_rank handles: rank 0 calls qsv_comm_unique_id, the host
+ * side broadcasts the 128 bytes, every rank calls qsv_comm_init (collective). */
+int qsv_comm_unique_id(uint8_t id[QSV_UNIQUE_ID_BYTES]);
+int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES]);
+
+int qsv_destroy(qsv_handle* h);
+int qsv_sync(qsv_handle* h);
+
+/* ---- state preparation -------------------------------------------------------------- */
+
+/* |0...0>  -- implicit initial state of a QuantumCircuit (QCMRF.py:78). */
+int qsv_init_zero(qsv_handle* h);
+
+/* H on every qubit of qubit_mask applied to |0...0>, written directly:
+ * amp = 2^{-popcount/2} where (index & ~mask) == 0, else 0.   (QCMRF.py:204-205) */
+int qsv_init_uniform(qsv_handle* h, uint64_t qubit_mask);
+
+/* ---- gates -------------------------------------------------------------------------- */
+
+/* dense 2x2 on qubit t; m = row-major {re,im} x 4.   h / sx (QCMRF.py:231,236; basis 'sx'
+ * run_experiment.py:52). */
+int qsv_apply_1q(qsv_handle* h, int t, const double m[8]);
+
+/* multi-controlled 2x2: fires where bit ctrls[i] == ctrl_vals[i] (NULL = all ones). */
+int qsv_apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals,
+                   int t, const double m[8]);
+
+/* X / CX / CCX / MCX(k) with +-control flags: the AND gate of QCMRF.py:224-225,227, the
+ * x of QCMRF.py:233,235, basis 'cx','x'. */
+int qsv_apply_mcx(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t);
+
+/* k-qubit diagonal: amp[i] *= table[j], j = sum_b bit(i, qubits[b]) << b; table = 2^k x {re,im}.
+ * rz / p / merged phase blocks (cU_C of QCMRF.py:218-228 is one such table). */
+int qsv_apply_diag(qsv_handle* h, int k, const int* qubits, const double* table);
+
+/* e^{i angle} on the subspace where bit ctrls[i] == ctrl_vals[i] for all i (n_ctrl >= 1).
+ * cp(2 gamma, n, anc) of QCMRF.py:226 is n_ctrl = 2. */
+int qsv_apply_mcphase(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals,
+                      double angle);
+
+/* uniformly controlled 2x2 on t: mats[j] (8 doubles each), j = control bits, ctrls[0] = LSB.
+ * The whole real-part-extraction sandwich H cU X cU^dg X H of QCMRF.py:231-236 is one of
+ * these. */
+int qsv_apply_mux_1q(qsv_handle* h, int k, const int* ctrls, int t, const double* mats);
+
+/* dense 2^k x 2^k unitary (k <= QSV_MAX_KQ), row-major {re,im}; index bit b <-> qubits[b].
+ * Fused blocks of a transpiled circuit (run_experiment.py:52). */
+int qsv_apply_kq(qsv_handle* h, int k, const int* qubits, const double* u);
+
+/* physically swap the amplitude-index positions a[i] <-> b[i].  Both local: a permutation
+ * sweep.  One of them a shard bit: the pairwise half-shard exchange (device copy for
+ * virtual shards, peer copy between devices of one process, RCCL send/recv between ranks). */
+int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const int* b);
+
+/* ---- measurement (QCMRF.py:239,243; shots of run_experiment.py:56) -------------------- */
+
+/* marginal distribution over `qubits` (k <= 26): out[j] += sum |amp|^2, j as in qsv_apply_diag.
+ * Only amplitudes with (index & fix_mask) == fix_val contribute (fix_mask = 0: all).
+ * Multi-process handles return this rank's partial sums. */
+int qsv_probabilities(qsv_handle* h, const int* qubits, int k, double* out);
+int qsv_probabilities_cond(qsv_handle* h, const int* qubits, int k,
+                           uint64_t fix_mask, uint64_t fix_val, double* out);
+
+/* sum |amp|^2 over this process's shards */
+int qsv_norm(qsv_handle* h, double* out);
+
+/* draw `shots` basis states from |amp|^2 over this process's shards (normalised by their
+ * mass); out_bits[s] bit j = value of qubit meas_qubits[j] (n_meas <= 64).
+ * meas_qubits == NULL: out_bits[s] = the full basis index. */
+int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const int* meas_qubits,
+               int n_meas, uint64_t* out_bits);
+
+/* copy amplitudes [start, start+count) of the GLOBAL index space into out (2*count doubles);
+ * the range must lie inside shards owned by this process. */
+int qsv_get_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, double* out);
+int qsv_set_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, const double* in);
+
+/* ---- batched execution -------------------------------------------------------------- */
+
+enum {
+  QSV_OP_INIT_ZERO = 0, QSV_OP_INIT_UNIFORM, QSV_OP_1Q, QSV_OP_MCX, QSV_OP_DIAG,
+  QSV_OP_MCPHASE, QSV_OP_MUX, QSV_OP_KQ, QSV_OP_SWAP
+};
+
+typedef struct {
+  int32_t  kind;                   /* QSV_OP_*                                             */
+  int32_t  target;                 /* target qubit (1Q, MCX, MUX)                          */
+  int32_t  n;                      /* number of controls / qubits in qubits[]              */
+  int32_t  pad;
+  int32_t  qubits[QSV_MAX_CTRL];   /* controls, or qubit list (DIAG, KQ), or swap a-list   */
+  int32_t  vals[QSV_MAX_CTRL];     /* control values, or swap b-list                       */
+  uint64_t data_off;               /* offset in doubles into `data` (matrix / table)       */
+  uint64_t mask;                   /* INIT_UNIFORM qubit mask                              */
+  double   angle;                  /* MCPHASE                                              */
+} qsv_op;
+
+/* run a whole program in one call (one ctypes crossing per circuit) */
+int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const double* data, uint64_t n_data);
+
+/* ---- instrumentation ---------------------------------------------------------------- */
+
+/* on: bracket every kernel launch with HIP events on its own stream (costs a little) */
+int qsv_set_profiling(qsv_handle* h, int on);
+int qsv_reset_stats(qsv_handle* h);
+int qsv_get_stats(qsv_handle* h, qsv_stats* out);
+
+/* HIP-event stopwatch on shard 0's stream: begin records, end records+synchronises */
+int qsv_timer_begin(qsv_handle* h);
+int qsv_timer_end(qsv_handle* h, double* ms);
+
+/* tuning knobs: "grid_cap", "unroll", "lowt_shuffle", "nontemporal" ... (-1 if unknown) */
+int qsv_set_option(qsv_handle* h, const char* name, int value);
+
+const char* qsv_last_error(void);
+const char* qsv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSV_H */

@@ -1,0 +1,172 @@
+"""Sharded numpy stand-in for the device engine.  TEST INFRASTRUCTURE ONLY.
+
+Same method names and physical-qubit semantics as ``qcmrf_amd._lib.Engine`` (which binds the
+HIP library), so the host-side planner / program logic can be exercised on CPU and so the
+N>1 path can be run across real processes over gloo (tests/test_multiproc_gloo.py).
+The shipped package never imports this.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import sv_numpy as sv
+
+_X = sv.MATS["x"]
+
+
+class NumpyEngine:
+    def __init__(self, n_qubits, n_shards=1, owned=None, exchange=None):
+        """owned: shard numbers held by this process (default: all).
+        exchange(my_shard_no, peer_shard_no, send_array) -> received array, for shards not owned."""
+        self.n_qubits = n_qubits
+        self.world = n_shards
+        self.g = n_shards.bit_length() - 1
+        self.L = n_qubits - self.g
+        self.local_qubits = self.L
+        self.owned = list(range(n_shards)) if owned is None else list(owned)
+        self.sh = {s: np.zeros(2 ** self.L, dtype=np.complex128) for s in self.owned}
+        self._exchange = exchange
+        self.n_exchanges = 0
+
+    # ---- helpers
+    def _bit(self, s, q):
+        return (s >> (q - self.L)) & 1
+
+    def _local_ctrl(self, s, ctrls, vals):
+        lq, lv = [], []
+        for c, v in zip(ctrls, vals):
+            if c >= self.L:
+                if self._bit(s, c) != v:
+                    return None
+            else:
+                lq.append(c)
+                lv.append(v)
+        return lq, lv
+
+    def _slice(self, s, qubits, table, ent_shape):
+        table = np.asarray(table, dtype=np.complex128).reshape((-1,) + ent_shape)
+        lq, lpos, gfix = [], [], 0
+        for b, q in enumerate(qubits):
+            if q >= self.L:
+                gfix |= self._bit(s, q) << b
+            else:
+                lq.append(q)
+                lpos.append(b)
+        sub = []
+        for jl in range(2 ** len(lq)):
+            j = gfix
+            for b, pos in enumerate(lpos):
+                j |= ((jl >> b) & 1) << pos
+            sub.append(table[j])
+        return lq, np.array(sub)
+
+    # ---- state preparation
+    def init_zero(self):
+        self.init_uniform(0)
+
+    def init_uniform(self, mask):
+        val = 2.0 ** (-0.5 * bin(mask).count("1"))
+        idx = np.arange(2 ** self.L, dtype=np.int64)
+        for s in self.owned:
+            g = (s << self.L) | idx
+            self.sh[s][:] = np.where((g & ~mask) == 0, val, 0.0)
+
+    # ---- gates
+    def apply_1q(self, t, m, ctrls=(), ctrl_vals=None):
+        assert t < self.L, "dense target on a shard bit"
+        vals = [1] * len(ctrls) if ctrl_vals is None else list(ctrl_vals)
+        for s in self.owned:
+            lc = self._local_ctrl(s, ctrls, vals)
+            if lc is not None:
+                sv.apply_1q(self.sh[s], t, np.asarray(m).reshape(2, 2), lc[0], lc[1])
+
+    def apply_mcx(self, ctrls, t, ctrl_vals=None):
+        self.apply_1q(t, _X, ctrls, ctrl_vals)
+
+    def apply_mcphase(self, qubits, angle, vals=None):
+        vals = [1] * len(qubits) if vals is None else list(vals)
+        for s in self.owned:
+            lc = self._local_ctrl(s, qubits, vals)
+            if lc is not None:
+                if lc[0]:
+                    sv.apply_mcphase(self.sh[s], lc[0], angle, lc[1])
+                else:
+                    self.sh[s] *= np.exp(1j * angle)
+
+    def apply_diag(self, qubits, table):
+        for s in self.owned:
+            lq, sub = self._slice(s, qubits, table, ())
+            if lq:
+                sv.apply_diag(self.sh[s], lq, sub)
+            else:
+                self.sh[s] *= sub[0]
+
+    def apply_mux(self, ctrls, t, mats):
+        assert t < self.L
+        for s in self.owned:
+            lq, sub = self._slice(s, ctrls, mats, (2, 2))
+            sv.apply_mux(self.sh[s], lq, t, sub)
+
+    def apply_kq(self, qubits, u):
+        assert all(q < self.L for q in qubits)
+        for s in self.owned:
+            sv.apply_kq(self.sh[s], list(qubits), u)
+
+    def swap_layout(self, a, b):
+        for x, y in zip(a, b):
+            lo, hi = min(x, y), max(x, y)
+            if lo == hi:
+                continue
+            if hi < self.L:
+                for s in self.owned:
+                    st = self.sh[s]
+                    idx = np.arange(st.size)
+                    sel = idx[(((idx >> lo) & 1) == 1) & (((idx >> hi) & 1) == 0)]
+                    other = sel ^ (1 << lo) ^ (1 << hi)
+                    st[sel], st[other] = st[other].copy(), st[sel].copy()
+            else:
+                assert lo < self.L, "swap of two shard bits"
+                self._exchange_bit(hi, lo)
+
+    def _exchange_bit(self, G, j):
+        self.n_exchanges += 1
+        gb = G - self.L
+        idx = np.arange(2 ** self.L)
+        done = set()
+        for s in self.owned:
+            if s in done:
+                continue
+            u = (s >> gb) & 1
+            peer = s ^ (1 << gb)
+            region = idx[((idx >> j) & 1) == (1 - u)]        # my entries that travel
+            if peer in self.sh:
+                pregion = idx[((idx >> j) & 1) == u]
+                a, b = self.sh[s][region].copy(), self.sh[peer][pregion].copy()
+                self.sh[s][region], self.sh[peer][pregion] = b, a
+                done.update((s, peer))
+            else:
+                self.sh[s][region] = self._exchange(s, peer, self.sh[s][region].copy())
+                done.add(s)
+
+    # ---- measurement
+    def norm(self):
+        return float(sum((np.abs(v) ** 2).sum() for v in self.sh.values()))
+
+    def amplitudes(self, start=0, count=None):
+        full = np.concatenate([self.sh[s] for s in sorted(self.sh)])
+        base = min(self.sh) << self.L
+        count = full.size - (start - base) if count is None else count
+        return full[start - base: start - base + count].copy()
+
+    def sample(self, shots, seed, meas_qubits=None):
+        owned = sorted(self.sh)
+        p = np.concatenate([np.abs(self.sh[s]) ** 2 for s in owned])
+        gidx = np.concatenate([(s << self.L) | np.arange(2 ** self.L) for s in owned]).astype(np.uint64)
+        rng = np.random.RandomState(seed % (2 ** 32))
+        pick = gidx[rng.choice(p.size, size=shots, p=p / p.sum())]
+        if meas_qubits is None:
+            return pick
+        out = np.zeros(shots, dtype=np.uint64)
+        for b, q in enumerate(meas_qubits):
+            out |= ((pick >> np.uint64(q)) & np.uint64(1)) << np.uint64(b)
+        return out

@@ -1,0 +1,51 @@
+"""Host-side process group used when one process drives one GPU (torchrun-style launch).
+
+Only tiny host values travel here (per-shard probability mass, sampled outcomes, the RCCL
+unique id); amplitudes move between GPUs inside libqsv over RCCL/xGMI, never through Python.
+``torch.distributed`` is imported lazily and only by ``TorchDistComm`` -- the single-GPU path
+never imports torch.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+
+class SingleProcess:
+    rank = 0
+    world = 1
+
+    def allgather(self, obj):
+        return [obj]
+
+    def bcast(self, obj, src=0):
+        return obj
+
+    def barrier(self):
+        pass
+
+
+class TorchDistComm:
+    """torch.distributed (gloo by default: host objects only) behind the same four calls."""
+
+    def __init__(self, backend="gloo", init=True):
+        import torch.distributed as dist
+        self._dist = dist
+        if init and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend)
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def allgather(self, obj):
+        out = [None] * self.world
+        self._dist.all_gather_object(out, obj)
+        return out
+
+    def bcast(self, obj, src=0):
+        box = [obj if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def barrier(self):
+        self._dist.barrier()

@@ -1,0 +1,1054 @@
+// qsv.hip -- host side of libqsv.so: handles, shard resolution, launches, sampling, exchange.
+// C ABI declared in include/qsv.h (which cites the reference call each entry point replaces).
+// gfx950 only; no CPU fallback of any kind: without a HIP device every entry point fails.
+#include "qsv_kernels.h"
+#include "../../include/qsv.h"
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(e_ == hipErrorOutOfMemory ? QSV_E_NOMEM : QSV_E_HIP, "%s: %s (%s:%d)",   \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+  } while (0)
+#define CHK(expr)                 \
+  do {                            \
+    int r_ = (expr);              \
+    if (r_ != QSV_OK) return r_;  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// RCCL, bound lazily (dlopen) so single-GPU use never touches it
+// ------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+  if (g_rccl.lib) return QSV_OK;
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(QSV_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+#define BIND(field, sym)                                                        \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, sym));     \
+  if (!g_rccl.field) return fail(QSV_E_RCCL, "librccl lacks %s", sym)
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(Send, "ncclSend");
+  BIND(Recv, "ncclRecv");
+  BIND(GroupStart, "ncclGroupStart");
+  BIND(GroupEnd, "ncclGroupEnd");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  g_rccl.lib = lib;
+  return QSV_OK;
+}
+#define NCCLCHK(expr)                                                                     \
+  do {                                                                                    \
+    ncclResult_t r_ = (expr);                                                             \
+    if (r_ != ncclSuccess)                                                                \
+      return fail(QSV_E_RCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_));                \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct Pending { int kind; hipEvent_t e0, e1; };
+
+struct Shard {
+  int device = 0;
+  int index = 0;                 // global shard number (= rank in multi-process mode)
+  hipStream_t stream = nullptr;
+  cplx* amp = nullptr;
+  // small-table arena: pinned host staging + device mirror, bump allocated
+  char* h_arena = nullptr;
+  char* d_arena = nullptr;
+  size_t arena_bytes = 0, arena_top = 0;
+  // sampling workspace
+  double* d_sums = nullptr;      // one per QSV_SBLOCK amplitudes
+  // exchange staging (allocated on first use)
+  cplx* xbuf[2] = {nullptr, nullptr};
+  size_t xbuf_amps = 0;
+  int n_cu = 256;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+};
+
+struct qsv_handle {
+  int W = 0, L = 0, gbits = 0;   // global qubits, local qubits per shard, shard bits
+  int P = 1;                     // total shards
+  bool multiproc = false;
+  int rank = 0;
+  ncclComm_t comm = nullptr;
+  std::vector<Shard> shards;     // shards owned by this process
+  qsv_stats stats;
+  bool profiling = false;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // options
+  int opt_blocks_per_cu = 8;
+  int opt_unroll = 4;
+  int opt_lowt_shuffle = 1;
+  int opt_nt = 0;
+  uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
+};
+
+static inline uint64_t amps_local(const qsv_handle* h) { return 1ull << h->L; }
+
+static int shard_set(const Shard& s) {
+  HIPCHK(hipSetDevice(s.device));
+  return QSV_OK;
+}
+
+static unsigned grid_for(const qsv_handle* h, const Shard& s, uint64_t work, uint64_t per_block) {
+  uint64_t need = (work + per_block - 1) / per_block;
+  uint64_t cap = (uint64_t)s.n_cu * (uint64_t)h->opt_blocks_per_cu;
+  if (need < 1) need = 1;
+  return (unsigned)std::min(need, cap);
+}
+
+// device copy of a small host table, asynchronous on the shard stream
+static int arena_put(Shard& s, const void* src, size_t bytes, void** dptr) {
+  const size_t slot = (bytes + 255) & ~size_t(255);
+  if (slot > s.arena_bytes) return fail(QSV_E_BADARG, "table of %zu bytes exceeds arena", bytes);
+  if (s.arena_top + slot > s.arena_bytes) {
+    HIPCHK(hipStreamSynchronize(s.stream));   // every earlier table has been consumed
+    s.arena_top = 0;
+  }
+  memcpy(s.h_arena + s.arena_top, src, bytes);
+  HIPCHK(hipMemcpyAsync(s.d_arena + s.arena_top, s.h_arena + s.arena_top, bytes,
+                        hipMemcpyHostToDevice, s.stream));
+  *dptr = s.d_arena + s.arena_top;
+  s.arena_top += slot;
+  return QSV_OK;
+}
+
+static int get_event(Shard& s, hipEvent_t* e) {
+  if (!s.free_events.empty()) { *e = s.free_events.back(); s.free_events.pop_back(); return QSV_OK; }
+  HIPCHK(hipEventCreate(e));
+  return QSV_OK;
+}
+
+static int drain_pending(qsv_handle* h) {
+  for (Shard& s : h->shards) {
+    if (s.pending.empty()) continue;
+    CHK(shard_set(s));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    for (Pending& p : s.pending) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, p.e0, p.e1));
+      h->stats.per_kind[p.kind].device_ms += ms;
+      s.free_events.push_back(p.e0);
+      s.free_events.push_back(p.e1);
+    }
+    s.pending.clear();
+  }
+  return QSV_OK;
+}
+
+// bracket one kernel launch: stats (+ events when profiling)
+template <class F>
+static int launch(qsv_handle* h, Shard& s, int kind, double bytes, F&& f) {
+  Pending p{kind, nullptr, nullptr};
+  if (h->profiling) {
+    CHK(get_event(s, &p.e0));
+    CHK(get_event(s, &p.e1));
+    HIPCHK(hipEventRecord(p.e0, s.stream));
+  }
+  f();
+  HIPCHK(hipGetLastError());
+  if (h->profiling) {
+    HIPCHK(hipEventRecord(p.e1, s.stream));
+    s.pending.push_back(p);
+    if (s.pending.size() > 4096) CHK(drain_pending(h));
+  }
+  h->stats.per_kind[kind].launches += 1;
+  h->stats.per_kind[kind].algorithmic_bytes += bytes;
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// life cycle
+// ------------------------------------------------------------------------------------------
+static int shard_alloc(qsv_handle* h, Shard& s) {
+  CHK(shard_set(s));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, s.device));
+  s.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  const uint64_t n = amps_local(h);
+  HIPCHK(hipMalloc(&s.amp, n * sizeof(cplx)));
+  s.arena_bytes = 8u << 20;
+  HIPCHK(hipHostMalloc(&s.h_arena, s.arena_bytes, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&s.d_arena, s.arena_bytes));
+  const uint64_t nblk = (n + QSV_SBLOCK - 1) / QSV_SBLOCK;
+  HIPCHK(hipMalloc(&s.d_sums, nblk * sizeof(double)));
+  return QSV_OK;
+}
+
+static int ilog2_exact(int x) {
+  if (x <= 0 || (x & (x - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return l;
+}
+
+extern "C" int qsv_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(QSV_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+static int create_common(int n_qubits, int P, qsv_handle** out, qsv_handle** hh) {
+  if (!out) return fail(QSV_E_BADARG, "out is NULL");
+  const int g = ilog2_exact(P);
+  if (g < 0) return fail(QSV_E_BADARG, "number of shards %d is not a power of two", P);
+  if (n_qubits < 1 || n_qubits > 40) return fail(QSV_E_BADARG, "n_qubits %d out of range", n_qubits);
+  if (n_qubits - g < 1) return fail(QSV_E_BADARG, "%d qubits cannot be split into %d shards", n_qubits, P);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(QSV_E_HIP, "no HIP device visible");
+  qsv_handle* h = new qsv_handle();
+  memset(&h->stats, 0, sizeof h->stats);
+  h->W = n_qubits;
+  h->gbits = g;
+  h->L = n_qubits - g;
+  h->P = P;
+  *hh = h;
+  return QSV_OK;
+}
+
+extern "C" int qsv_destroy(qsv_handle* h) {
+  if (!h) return QSV_OK;
+  for (Shard& s : h->shards) {
+    hipSetDevice(s.device);
+    if (s.stream) hipStreamSynchronize(s.stream);
+    for (Pending& p : s.pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+    for (hipEvent_t e : s.free_events) hipEventDestroy(e);
+    if (s.amp) hipFree(s.amp);
+    if (s.d_arena) hipFree(s.d_arena);
+    if (s.h_arena) hipHostFree(s.h_arena);
+    if (s.d_sums) hipFree(s.d_sums);
+    for (int b = 0; b < 2; ++b) if (s.xbuf[b]) hipFree(s.xbuf[b]);
+    if (s.stream) hipStreamDestroy(s.stream);
+  }
+  if (h->t0) hipEventDestroy(h->t0);
+  if (h->t1) hipEventDestroy(h->t1);
+  if (h->comm && g_rccl.lib) g_rccl.CommDestroy(h->comm);
+  delete h;
+  return QSV_OK;
+}
+
+extern "C" int qsv_create(int n_qubits, int n_devices, const int* device_ids, qsv_handle** out) {
+  qsv_handle* h = nullptr;
+  CHK(create_common(n_qubits, n_devices, out, &h));
+  int ndev = 0;
+  hipGetDeviceCount(&ndev);
+  h->shards.resize(n_devices);
+  for (int i = 0; i < n_devices; ++i) {
+    Shard& s = h->shards[i];
+    s.device = device_ids ? device_ids[i] : 0;
+    s.index = i;
+    if (s.device < 0 || s.device >= ndev) {
+      qsv_destroy(h);
+      return fail(QSV_E_BADARG, "device id %d not in [0,%d)", s.device, ndev);
+    }
+    int r = shard_alloc(h, s);
+    if (r != QSV_OK) { qsv_destroy(h); return r; }
+  }
+  // peer access between distinct devices of one process (exchange by peer copy)
+  for (Shard& a : h->shards)
+    for (Shard& b : h->shards)
+      if (a.device != b.device) {
+        int can = 0;
+        hipDeviceCanAccessPeer(&can, a.device, b.device);
+        if (can) { hipSetDevice(a.device); hipDeviceEnablePeerAccess(b.device, 0); (void)hipGetLastError(); }
+      }
+  *out = h;
+  return QSV_OK;
+}
+
+extern "C" int qsv_create_rank(int n_qubits, int world_size, int rank, int device_id, qsv_handle** out) {
+  qsv_handle* h = nullptr;
+  CHK(create_common(n_qubits, world_size, out, &h));
+  if (rank < 0 || rank >= world_size) { delete h; return fail(QSV_E_BADARG, "rank %d not in [0,%d)", rank, world_size); }
+  int ndev = 0;
+  hipGetDeviceCount(&ndev);
+  if (device_id < 0 || device_id >= ndev) { delete h; return fail(QSV_E_BADARG, "device id %d not in [0,%d)", device_id, ndev); }
+  h->multiproc = world_size > 1;
+  h->rank = rank;
+  h->shards.resize(1);
+  h->shards[0].device = device_id;
+  h->shards[0].index = rank;
+  int r = shard_alloc(h, h->shards[0]);
+  if (r != QSV_OK) { qsv_destroy(h); return r; }
+  *out = h;
+  return QSV_OK;
+}
+
+extern "C" int qsv_comm_unique_id(uint8_t id[QSV_UNIQUE_ID_BYTES]) {
+  CHK(rccl_load());
+  ncclUniqueId uid;
+  NCCLCHK(g_rccl.GetUniqueId(&uid));
+  static_assert(sizeof(uid) == QSV_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  memcpy(id, &uid, QSV_UNIQUE_ID_BYTES);
+  return QSV_OK;
+}
+
+extern "C" int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES]) {
+  if (!h || !id) return fail(QSV_E_BADARG, "NULL argument");
+  if (!h->multiproc) return QSV_OK;
+  if (h->comm) return QSV_OK;
+  CHK(rccl_load());
+  CHK(shard_set(h->shards[0]));
+  ncclUniqueId uid;
+  memcpy(&uid, id, QSV_UNIQUE_ID_BYTES);
+  NCCLCHK(g_rccl.CommInitRank(&h->comm, h->P, uid, h->rank));
+  return QSV_OK;
+}
+
+extern "C" int qsv_sync(qsv_handle* h) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    HIPCHK(hipStreamSynchronize(s.stream));
+  }
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// shard resolution helpers
+// ------------------------------------------------------------------------------------------
+static int check_qubit(const qsv_handle* h, int q, const char* what) {
+  if (q < 0 || q >= h->W) return fail(QSV_E_BADARG, "%s qubit %d not in [0,%d)", what, q, h->W);
+  return QSV_OK;
+}
+static inline int shard_bit(const qsv_handle* h, const Shard& s, int q) {   // q >= L
+  return (s.index >> (q - h->L)) & 1;
+}
+
+// controls -> (skip shard?, local controls)
+struct LocalCtrl { bool skip = false; std::vector<int> q, v; };
+static LocalCtrl resolve_ctrl(const qsv_handle* h, const Shard& s, int n, const int* ctrls, const int* vals) {
+  LocalCtrl lc;
+  for (int i = 0; i < n; ++i) {
+    const int v = vals ? (vals[i] ? 1 : 0) : 1;
+    if (ctrls[i] >= h->L) { if (shard_bit(h, s, ctrls[i]) != v) lc.skip = true; }
+    else { lc.q.push_back(ctrls[i]); lc.v.push_back(v); }
+  }
+  return lc;
+}
+
+static int check_distinct(const qsv_handle* h, int n, const int* q, int extra) {
+  uint64_t seen = 0;
+  if (extra >= 0) seen |= 1ull << extra;
+  for (int i = 0; i < n; ++i) {
+    CHK(check_qubit(h, q[i], "gate"));
+    if (seen & (1ull << q[i])) return fail(QSV_E_BADARG, "duplicate qubit %d in gate", q[i]);
+    seen |= 1ull << q[i];
+  }
+  return QSV_OK;
+}
+
+static BitIns make_ins(std::vector<int> pos) {
+  std::sort(pos.begin(), pos.end());
+  BitIns b;
+  b.n = (int)pos.size();
+  for (int i = 0; i < b.n; ++i) b.pos[i] = pos[i];
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------
+// state preparation
+// ------------------------------------------------------------------------------------------
+extern "C" int qsv_init_uniform(qsv_handle* h, uint64_t qubit_mask) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (h->W < 64 && (qubit_mask >> h->W)) return fail(QSV_E_BADARG, "mask has bits beyond qubit %d", h->W - 1);
+  const int pc = __builtin_popcountll(qubit_mask);
+  const double val = std::pow(2.0, -0.5 * pc);
+  const uint64_t n = amps_local(h);
+  const uint64_t lmask = n - 1;
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    // shard bits outside the mask must be 0 for the shard to hold any weight
+    const uint64_t hi = (uint64_t)s.index << h->L;
+    const double v = (hi & ~qubit_mask) ? 0.0 : val;
+    const uint64_t nonmask = ~qubit_mask & lmask;
+    CHK(launch(h, s, QSV_K_INIT, 16.0 * (double)n, [&] {
+      hipLaunchKernelGGL(k_init, dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
+                         s.amp, n, nonmask, v);
+    }));
+  }
+  return QSV_OK;
+}
+extern "C" int qsv_init_zero(qsv_handle* h) { return qsv_init_uniform(h, 0ull); }
+
+// ------------------------------------------------------------------------------------------
+// (multi-controlled) 2x2 and X
+// ------------------------------------------------------------------------------------------
+template <int KIND, bool NT>
+static void launch_pair(const qsv_handle* h, const Shard& s, uint64_t npairs, const BitIns& ins,
+                        uint64_t fixed, uint64_t tbit, const Mat2& m) {
+  const int U = h->opt_unroll;
+  if (U >= 4 && npairs % (QSV_TPB * 4) == 0)
+    hipLaunchKernelGGL((k_pair<KIND, 4, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 4)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+  else if (U >= 2 && npairs % (QSV_TPB * 2) == 0)
+    hipLaunchKernelGGL((k_pair<KIND, 2, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 2)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+  else
+    hipLaunchKernelGGL((k_pair<KIND, 1, true, NT>), dim3(grid_for(h, s, npairs, QSV_TPB)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+}
+
+static int apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* vals, int t,
+                      const double* m, bool is_x) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (n_ctrl < 0 || n_ctrl > QSV_MAX_CTRL) return fail(QSV_E_BADARG, "n_ctrl %d out of range", n_ctrl);
+  if (n_ctrl && !ctrls) return fail(QSV_E_BADARG, "ctrls is NULL");
+  CHK(check_qubit(h, t, "target"));
+  CHK(check_distinct(h, n_ctrl, ctrls, t));
+  if (t >= h->L)
+    return fail(QSV_E_UNSUPPORTED, "target qubit %d is a shard bit (local qubits: %d); qsv_swap_layout it first", t, h->L);
+  Mat2 mm;
+  if (is_x) memset(&mm, 0, sizeof mm);
+  else {
+    if (!m) return fail(QSV_E_BADARG, "matrix is NULL");
+    memcpy(mm.v, m, sizeof mm.v);
+  }
+  const uint64_t n = amps_local(h);
+  for (Shard& s : h->shards) {
+    LocalCtrl lc = resolve_ctrl(h, s, n_ctrl, ctrls, vals);
+    if (lc.skip) continue;
+    CHK(shard_set(s));
+    const int nc = (int)lc.q.size();
+    const uint64_t npairs = n >> (1 + nc);
+    const double bytes = 32.0 * (double)(n >> nc);
+    const int kind = is_x ? QSV_K_X : QSV_K_1Q;
+    // low target, no controls, dense: wave-shuffle kernel
+    if (!is_x && nc == 0 && t < 6 && h->opt_lowt_shuffle && n % (QSV_TPB * 4) == 0) {
+      CHK(launch(h, s, kind, bytes, [&] {
+        if (h->opt_nt)
+          hipLaunchKernelGGL((k_lowt<4, true>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
+                             s.amp, n, t, mm);
+        else
+          hipLaunchKernelGGL((k_lowt<4, false>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
+                             s.amp, n, t, mm);
+      }));
+      continue;
+    }
+    std::vector<int> pos = lc.q;
+    pos.push_back(t);
+    const BitIns ins = make_ins(pos);
+    uint64_t fixed = 0;
+    for (int i = 0; i < nc; ++i) if (lc.v[i]) fixed |= 1ull << lc.q[i];
+    const uint64_t tbit = 1ull << t;
+    CHK(launch(h, s, kind, bytes, [&] {
+      if (is_x) { if (h->opt_nt) launch_pair<1, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<1, false>(h, s, npairs, ins, fixed, tbit, mm); }
+      else      { if (h->opt_nt) launch_pair<0, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<0, false>(h, s, npairs, ins, fixed, tbit, mm); }
+    }));
+  }
+  return QSV_OK;
+}
+
+extern "C" int qsv_apply_1q(qsv_handle* h, int t, const double m[8]) { return apply_mc1q(h, 0, nullptr, nullptr, t, m, false); }
+extern "C" int qsv_apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t, const double m[8]) {
+  return apply_mc1q(h, n_ctrl, ctrls, ctrl_vals, t, m, false);
+}
+extern "C" int qsv_apply_mcx(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t) {
+  return apply_mc1q(h, n_ctrl, ctrls, ctrl_vals, t, nullptr, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// diagonal family
+// ------------------------------------------------------------------------------------------
+extern "C" int qsv_apply_mcphase(qsv_handle* h, int n_ctrl, const int* ctrls, const int* vals, double angle) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (n_ctrl < 1 || n_ctrl > QSV_MAX_CTRL || !ctrls) return fail(QSV_E_BADARG, "mcphase needs 1..%d qubits", QSV_MAX_CTRL);
+  CHK(check_distinct(h, n_ctrl, ctrls, -1));
+  const cplx ph = make_double2(std::cos(angle), std::sin(angle));
+  const uint64_t n = amps_local(h);
+  for (Shard& s : h->shards) {
+    LocalCtrl lc = resolve_ctrl(h, s, n_ctrl, ctrls, vals);
+    if (lc.skip) continue;
+    CHK(shard_set(s));
+    const int nc = (int)lc.q.size();
+    const uint64_t nsub = n >> nc;
+    const BitIns ins = make_ins(lc.q);
+    uint64_t fixed = 0;
+    for (int i = 0; i < nc; ++i) if (lc.v[i]) fixed |= 1ull << lc.q[i];
+    CHK(launch(h, s, QSV_K_MCPHASE, 32.0 * (double)nsub, [&] {
+      if (nsub % (QSV_TPB * 4) == 0)
+        hipLaunchKernelGGL((k_mcphase<4, false>), dim3(grid_for(h, s, nsub, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
+                           s.amp, nsub, ins, fixed, ph);
+      else
+        hipLaunchKernelGGL((k_mcphase<1, true>), dim3(grid_for(h, s, nsub, QSV_TPB)), dim3(QSV_TPB), 0, s.stream,
+                           s.amp, nsub, ins, fixed, ph);
+    }));
+  }
+  return QSV_OK;
+}
+
+// slice a 2^k table (entry = `ent` doubles) over `qubits` down to the local qubits of shard s
+static void slice_table(const qsv_handle* h, const Shard& s, int k, const int* qubits, const double* table,
+                        int ent, std::vector<int>& lq, std::vector<double>& out) {
+  std::vector<int> lpos;   // positions (within the k-list) that are local
+  uint32_t gfix = 0;
+  lq.clear();
+  for (int b = 0; b < k; ++b) {
+    if (qubits[b] >= h->L) { if (shard_bit(h, s, qubits[b])) gfix |= 1u << b; }
+    else { lpos.push_back(b); lq.push_back(qubits[b]); }
+  }
+  const int kl = (int)lpos.size();
+  out.resize((size_t)ent << kl);
+  for (uint32_t jl = 0; jl < (1u << kl); ++jl) {
+    uint32_t j = gfix;
+    for (int b = 0; b < kl; ++b) if ((jl >> b) & 1u) j |= 1u << lpos[b];
+    memcpy(&out[(size_t)jl * ent], &table[(size_t)j * ent], sizeof(double) * ent);
+  }
+}
+
+extern "C" int qsv_apply_diag(qsv_handle* h, int k, const int* qubits, const double* table) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (k < 1 || k > QSV_MAX_CTRL || !qubits || !table) return fail(QSV_E_BADARG, "diag needs 1..%d qubits and a table", QSV_MAX_CTRL);
+  CHK(check_distinct(h, k, qubits, -1));
+  const uint64_t n = amps_local(h);
+  std::vector<int> lq;
+  std::vector<double> sub;
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    slice_table(h, s, k, qubits, table, 2, lq, sub);
+    const int kl = (int)lq.size();
+    const int ntab = 1 << kl;
+    void* dtab = nullptr;
+    CHK(arena_put(s, sub.data(), sub.size() * sizeof(double), &dtab));
+    BitList bl;
+    bl.n = kl;
+    for (int b = 0; b < kl; ++b) bl.pos[b] = lq[b];
+    const bool lds = kl <= 11;
+    const size_t shm = lds ? (size_t)ntab * sizeof(cplx) : 0;
+    CHK(launch(h, s, QSV_K_DIAG, 32.0 * (double)n, [&] {
+      const cplx* tp = reinterpret_cast<const cplx*>(dtab);
+      if (n % (QSV_TPB * 4) == 0) {
+        const dim3 g(grid_for(h, s, n, QSV_TPB * 4));
+        if (lds) {
+          if (h->opt_nt) hipLaunchKernelGGL((k_diag<4, false, true, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, n, bl, tp, ntab);
+          else           hipLaunchKernelGGL((k_diag<4, false, true, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, n, bl, tp, ntab);
+        } else           hipLaunchKernelGGL((k_diag<4, false, false, false>), g, dim3(QSV_TPB), 0, s.stream, s.amp, n, bl, tp, ntab);
+      } else {
+        const dim3 g(grid_for(h, s, n, QSV_TPB));
+        if (lds) hipLaunchKernelGGL((k_diag<1, true, true, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, n, bl, tp, ntab);
+        else     hipLaunchKernelGGL((k_diag<1, true, false, false>), g, dim3(QSV_TPB), 0, s.stream, s.amp, n, bl, tp, ntab);
+      }
+    }));
+  }
+  return QSV_OK;
+}
+
+extern "C" int qsv_apply_mux_1q(qsv_handle* h, int k, const int* ctrls, int t, const double* mats) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (k < 0 || k > 10 || (k && !ctrls) || !mats) return fail(QSV_E_BADARG, "mux needs 0..10 controls and matrices");
+  CHK(check_qubit(h, t, "target"));
+  CHK(check_distinct(h, k, ctrls, t));
+  if (t >= h->L)
+    return fail(QSV_E_UNSUPPORTED, "target qubit %d is a shard bit (local qubits: %d); qsv_swap_layout it first", t, h->L);
+  const uint64_t n = amps_local(h);
+  const uint64_t npairs = n >> 1;
+  std::vector<int> lq;
+  std::vector<double> sub;
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    slice_table(h, s, k, ctrls, mats, 8, lq, sub);
+    const int kl = (int)lq.size();
+    const int nmat = 1 << kl;
+    void* dtab = nullptr;
+    CHK(arena_put(s, sub.data(), sub.size() * sizeof(double), &dtab));
+    BitList bl;
+    bl.n = kl;
+    for (int b = 0; b < kl; ++b) bl.pos[b] = lq[b];
+    const size_t shm = (size_t)nmat * 64;
+    CHK(launch(h, s, QSV_K_MUX, 32.0 * (double)n, [&] {
+      const double* mp = reinterpret_cast<const double*>(dtab);
+      if (npairs % (QSV_TPB * 4) == 0 && h->opt_unroll >= 4) {
+        const dim3 g(grid_for(h, s, npairs, QSV_TPB * 4));
+        if (h->opt_nt) hipLaunchKernelGGL((k_mux<4, false, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+        else           hipLaunchKernelGGL((k_mux<4, false, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+      } else if (npairs % (QSV_TPB * 2) == 0) {
+        const dim3 g(grid_for(h, s, npairs, QSV_TPB * 2));
+        hipLaunchKernelGGL((k_mux<2, false, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+      } else {
+        const dim3 g(grid_for(h, s, npairs, QSV_TPB));
+        hipLaunchKernelGGL((k_mux<1, true, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+      }
+    }));
+  }
+  return QSV_OK;
+}
+
+template <int K>
+static void launch_kq(const qsv_handle* h, const Shard& s, uint64_t ngroups, const BitIns& ins,
+                      const KqOffs& offs, const cplx* u) {
+  const size_t shm = sizeof(cplx) << (2 * K);
+  hipLaunchKernelGGL((k_kq<K>), dim3(grid_for(h, s, ngroups, QSV_TPB)), dim3(QSV_TPB), shm, s.stream,
+                     s.amp, ngroups, ins, offs, u);
+}
+
+extern "C" int qsv_apply_kq(qsv_handle* h, int k, const int* qubits, const double* u) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (k < 1 || k > QSV_MAX_KQ || !qubits || !u) return fail(QSV_E_BADARG, "kq needs 1..%d qubits and a matrix", QSV_MAX_KQ);
+  CHK(check_distinct(h, k, qubits, -1));
+  for (int b = 0; b < k; ++b)
+    if (qubits[b] >= h->L)
+      return fail(QSV_E_UNSUPPORTED, "qubit %d of a dense gate is a shard bit (local qubits: %d); qsv_swap_layout it first", qubits[b], h->L);
+  if (h->L < k) return fail(QSV_E_BADARG, "dense %d-qubit gate on %d local qubits", k, h->L);
+  const uint64_t n = amps_local(h);
+  const uint64_t ngroups = n >> k;
+  KqOffs offs;
+  memset(&offs, 0, sizeof offs);
+  for (int j = 0; j < (1 << k); ++j)
+    for (int b = 0; b < k; ++b)
+      if ((j >> b) & 1) offs.off[j] |= 1ull << qubits[b];
+  const BitIns ins = make_ins(std::vector<int>(qubits, qubits + k));
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    void* dtab = nullptr;
+    CHK(arena_put(s, u, sizeof(double) * 2 << (2 * k), &dtab));
+    const cplx* up = reinterpret_cast<const cplx*>(dtab);
+    CHK(launch(h, s, QSV_K_KQ, 32.0 * (double)n, [&] {
+      switch (k) {
+        case 1: launch_kq<1>(h, s, ngroups, ins, offs, up); break;
+        case 2: launch_kq<2>(h, s, ngroups, ins, offs, up); break;
+        case 3: launch_kq<3>(h, s, ngroups, ins, offs, up); break;
+        case 4: launch_kq<4>(h, s, ngroups, ins, offs, up); break;
+        default: launch_kq<5>(h, s, ngroups, ins, offs, up); break;
+      }
+    }));
+  }
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout swaps and the shard-bit exchange
+// ------------------------------------------------------------------------------------------
+static int ensure_xbuf(qsv_handle* h, Shard& s, uint64_t amps) {
+  if (s.xbuf_amps >= amps) return QSV_OK;
+  CHK(shard_set(s));
+  for (int b = 0; b < 2; ++b) {
+    if (s.xbuf[b]) { HIPCHK(hipFree(s.xbuf[b])); s.xbuf[b] = nullptr; }
+    HIPCHK(hipMalloc(&s.xbuf[b], amps * sizeof(cplx)));
+  }
+  s.xbuf_amps = amps;
+  return QSV_OK;
+}
+
+static int swap_local(qsv_handle* h, int a, int b) {
+  if (a > b) std::swap(a, b);
+  const uint64_t n = amps_local(h);
+  const uint64_t nq = n >> 2;
+  const BitIns ins = make_ins({a, b});
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    CHK(launch(h, s, QSV_K_SWAP, 32.0 * (double)(n >> 1), [&] {
+      hipLaunchKernelGGL(k_swap_bits, dim3(grid_for(h, s, nq, QSV_TPB * 2)), dim3(QSV_TPB), 0, s.stream,
+                         s.amp, nq, ins, 1ull << a, 1ull << b);
+    }));
+  }
+  return QSV_OK;
+}
+
+// swap shard bit G (>= L) with local bit j
+static int exchange(qsv_handle* h, int G, int j) {
+  const int gb = G - h->L;
+  const uint64_t n = amps_local(h);
+  const uint64_t nhalf = n >> 1;
+  h->stats.exchanges += 1;
+  if (!h->multiproc) {
+    // every pair (A: bit gb = 0, B = A | 1<<gb) owned by this process
+    for (Shard& A : h->shards) {
+      if ((A.index >> gb) & 1) continue;
+      Shard& B = h->shards[A.index | (1 << gb)];
+      if (A.device == B.device) {
+        CHK(shard_set(A));
+        HIPCHK(hipStreamSynchronize(B.stream));
+        CHK(launch(h, A, QSV_K_EXCHANGE, 32.0 * (double)n, [&] {
+          hipLaunchKernelGGL(k_swap_shards, dim3(grid_for(h, A, nhalf, QSV_TPB * 2)), dim3(QSV_TPB), 0, A.stream,
+                             A.amp, B.amp, nhalf, j);
+        }));
+        HIPCHK(hipStreamSynchronize(A.stream));
+      } else {
+        const uint64_t chunk = std::min<uint64_t>(nhalf, h->opt_xchunk);
+        CHK(ensure_xbuf(h, A, chunk));
+        CHK(ensure_xbuf(h, B, chunk));
+        for (uint64_t p0 = 0; p0 < nhalf; p0 += chunk) {
+          CHK(shard_set(A));
+          hipLaunchKernelGGL(k_pack, dim3(grid_for(h, A, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, A.stream, A.amp, A.xbuf[0], p0, chunk, j, 1);
+          HIPCHK(hipGetLastError());
+          CHK(shard_set(B));
+          hipLaunchKernelGGL(k_pack, dim3(grid_for(h, B, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, B.stream, B.amp, B.xbuf[0], p0, chunk, j, 0);
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipStreamSynchronize(B.stream));
+          CHK(shard_set(A));
+          HIPCHK(hipStreamSynchronize(A.stream));
+          HIPCHK(hipMemcpyPeer(B.xbuf[1], B.device, A.xbuf[0], A.device, chunk * sizeof(cplx)));
+          HIPCHK(hipMemcpyPeer(A.xbuf[1], A.device, B.xbuf[0], B.device, chunk * sizeof(cplx)));
+          hipLaunchKernelGGL(k_unpack, dim3(grid_for(h, A, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, A.stream, A.amp, A.xbuf[1], p0, chunk, j, 1);
+          HIPCHK(hipGetLastError());
+          CHK(shard_set(B));
+          hipLaunchKernelGGL(k_unpack, dim3(grid_for(h, B, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, B.stream, B.amp, B.xbuf[1], p0, chunk, j, 0);
+          HIPCHK(hipGetLastError());
+          h->stats.exchange_bytes += 2.0 * (double)chunk * sizeof(cplx);
+        }
+        HIPCHK(hipStreamSynchronize(B.stream));
+        CHK(shard_set(A));
+        HIPCHK(hipStreamSynchronize(A.stream));
+        h->stats.per_kind[QSV_K_EXCHANGE].launches += 1;
+        h->stats.per_kind[QSV_K_EXCHANGE].algorithmic_bytes += 32.0 * (double)n;
+      }
+    }
+    return QSV_OK;
+  }
+  // one shard per process: RCCL send/recv with the partner rank, chunked through staging buffers
+  if (!h->comm) return fail(QSV_E_RCCL, "exchange needs qsv_comm_init on every rank first");
+  Shard& s = h->shards[0];
+  CHK(shard_set(s));
+  const int u = (s.index >> gb) & 1;
+  const int peer = s.index ^ (1 << gb);
+  const int v = 1 - u;                 // my entries with bit j == 1-u travel
+  const uint64_t chunk = std::min<uint64_t>(nhalf, h->opt_xchunk);
+  CHK(ensure_xbuf(h, s, chunk));
+  Pending p{QSV_K_EXCHANGE, nullptr, nullptr};
+  if (h->profiling) { CHK(get_event(s, &p.e0)); CHK(get_event(s, &p.e1)); HIPCHK(hipEventRecord(p.e0, s.stream)); }
+  for (uint64_t p0 = 0; p0 < nhalf; p0 += chunk) {
+    hipLaunchKernelGGL(k_pack, dim3(grid_for(h, s, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, s.stream, s.amp, s.xbuf[0], p0, chunk, j, v);
+    HIPCHK(hipGetLastError());
+    NCCLCHK(g_rccl.GroupStart());
+    NCCLCHK(g_rccl.Send(s.xbuf[0], chunk * 2, ncclDouble, peer, h->comm, s.stream));
+    NCCLCHK(g_rccl.Recv(s.xbuf[1], chunk * 2, ncclDouble, peer, h->comm, s.stream));
+    NCCLCHK(g_rccl.GroupEnd());
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for(h, s, chunk, QSV_TPB * 2)), dim3(QSV_TPB), 0, s.stream, s.amp, s.xbuf[1], p0, chunk, j, v);
+    HIPCHK(hipGetLastError());
+    h->stats.exchange_bytes += (double)chunk * sizeof(cplx);
+  }
+  if (h->profiling) { HIPCHK(hipEventRecord(p.e1, s.stream)); s.pending.push_back(p); }
+  h->stats.per_kind[QSV_K_EXCHANGE].launches += 1;
+  h->stats.per_kind[QSV_K_EXCHANGE].algorithmic_bytes += 32.0 * (double)nhalf;
+  return QSV_OK;
+}
+
+extern "C" int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const int* b) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (npairs < 0 || (npairs && (!a || !b))) return fail(QSV_E_BADARG, "bad swap list");
+  for (int i = 0; i < npairs; ++i) {
+    CHK(check_qubit(h, a[i], "swap"));
+    CHK(check_qubit(h, b[i], "swap"));
+    if (a[i] == b[i]) continue;
+    const int lo = std::min(a[i], b[i]), hi = std::max(a[i], b[i]);
+    if (hi < h->L) CHK(swap_local(h, lo, hi));
+    else if (lo < h->L) CHK(exchange(h, hi, lo));
+    else return fail(QSV_E_UNSUPPORTED, "swap of two shard bits (%d,%d) is not implemented; route through a local bit", lo, hi);
+  }
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------
+static int block_sums(qsv_handle* h, Shard& s, std::vector<double>& sums) {
+  const uint64_t n = amps_local(h);
+  const uint64_t nblk = (n + QSV_SBLOCK - 1) / QSV_SBLOCK;
+  CHK(shard_set(s));
+  CHK(launch(h, s, QSV_K_PROB, 16.0 * (double)n, [&] {
+    hipLaunchKernelGGL(k_blocksum, dim3((unsigned)std::min<uint64_t>(nblk, (uint64_t)s.n_cu * 16)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, n, s.d_sums, nblk);
+  }));
+  sums.resize(nblk);
+  HIPCHK(hipMemcpyAsync(sums.data(), s.d_sums, nblk * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  HIPCHK(hipStreamSynchronize(s.stream));
+  return QSV_OK;
+}
+
+static double pairwise_sum(const double* x, size_t n) {
+  if (n <= 64) { double s = 0; for (size_t i = 0; i < n; ++i) s += x[i]; return s; }
+  const size_t m = n / 2;
+  return pairwise_sum(x, m) + pairwise_sum(x + m, n - m);
+}
+
+extern "C" int qsv_norm(qsv_handle* h, double* out) {
+  if (!h || !out) return fail(QSV_E_BADARG, "NULL argument");
+  double tot = 0;
+  std::vector<double> sums;
+  for (Shard& s : h->shards) {
+    CHK(block_sums(h, s, sums));
+    tot += pairwise_sum(sums.data(), sums.size());
+  }
+  *out = tot;
+  return QSV_OK;
+}
+
+extern "C" int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const int* meas_qubits, int n_meas,
+                          uint64_t* out_bits) {
+  if (!h || (shots && !out_bits)) return fail(QSV_E_BADARG, "NULL argument");
+  if (meas_qubits && (n_meas < 0 || n_meas > 64)) return fail(QSV_E_BADARG, "n_meas %d out of range", n_meas);
+  if (meas_qubits) for (int i = 0; i < n_meas; ++i) CHK(check_qubit(h, meas_qubits[i], "measured"));
+  if (shots == 0) return QSV_OK;
+  const size_t ns = h->shards.size();
+  std::vector<std::vector<double>> sums(ns);
+  std::vector<double> mass(ns);
+  double total = 0;
+  for (size_t i = 0; i < ns; ++i) {
+    CHK(block_sums(h, h->shards[i], sums[i]));
+    mass[i] = pairwise_sum(sums[i].data(), sums[i].size());
+    total += mass[i];
+  }
+  if (!(total > 0)) return fail(QSV_E_BADARG, "state has zero norm on this process; nothing to sample");
+  // sorted uniforms in [0,total)
+  std::mt19937_64 rng(seed);
+  std::vector<double> r(shots);
+  for (uint64_t s = 0; s < shots; ++s) r[s] = (double)(rng() >> 11) * (1.0 / 9007199254740992.0) * total;
+  std::sort(r.begin(), r.end());
+  std::vector<uint64_t> idx(shots);
+  int last_shard = -1;
+  for (size_t i = 0; i < ns; ++i) if (mass[i] > 0) last_shard = (int)i;
+  uint64_t s0 = 0;
+  double base = 0;
+  for (size_t i = 0; i < ns && s0 < shots; ++i) {
+    if (!(mass[i] > 0)) continue;
+    Shard& sh = h->shards[i];
+    const double top = ((int)i == last_shard) ? INFINITY : base + mass[i];
+    uint64_t s1 = s0;
+    while (s1 < shots && r[s1] < top) ++s1;
+    const uint64_t cnt = s1 - s0;
+    if (cnt) {
+      // walk the blocks of this shard; rounding slack is clamped to the last populated block
+      std::vector<uint64_t> blk(cnt);
+      std::vector<double> res(cnt);
+      const std::vector<double>& bs = sums[i];
+      size_t last_nz = 0;
+      for (size_t bb = 0; bb < bs.size(); ++bb) if (bs[bb] > 0) last_nz = bb;
+      size_t b = 0;
+      double pre = base;                 // mass before block b
+      for (uint64_t q = 0; q < cnt; ++q) {
+        const double x = r[s0 + q];
+        while (b < last_nz && x >= pre + bs[b]) { pre += bs[b]; ++b; }
+        blk[q] = b;
+        res[q] = std::max(0.0, x - pre);
+      }
+      CHK(shard_set(sh));
+      uint64_t* d_blk = nullptr;
+      double* d_res = nullptr;
+      uint64_t* d_out = nullptr;
+      HIPCHK(hipMalloc(&d_blk, cnt * sizeof(uint64_t)));
+      HIPCHK(hipMalloc(&d_res, cnt * sizeof(double)));
+      HIPCHK(hipMalloc(&d_out, cnt * sizeof(uint64_t)));
+      HIPCHK(hipMemcpyAsync(d_blk, blk.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, sh.stream));
+      HIPCHK(hipMemcpyAsync(d_res, res.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sh.stream));
+      hipLaunchKernelGGL(k_locate, dim3((unsigned)std::min<uint64_t>(cnt, 65535)), dim3(64), 0, sh.stream,
+                         sh.amp, amps_local(h), d_blk, d_res, d_out, cnt);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&idx[s0], d_out, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, sh.stream));
+      HIPCHK(hipStreamSynchronize(sh.stream));
+      HIPCHK(hipFree(d_blk));
+      HIPCHK(hipFree(d_res));
+      HIPCHK(hipFree(d_out));
+      const uint64_t hi = (uint64_t)sh.index << h->L;
+      for (uint64_t q = 0; q < cnt; ++q) idx[s0 + q] |= hi;
+    }
+    base += mass[i];
+    s0 = s1;
+  }
+  // shots come out sorted by index; decorrelate the order with the same generator
+  for (uint64_t s = shots - 1; s > 0; --s) {
+    const uint64_t k = rng() % (s + 1);
+    std::swap(idx[s], idx[k]);
+  }
+  for (uint64_t s = 0; s < shots; ++s) {
+    if (!meas_qubits) { out_bits[s] = idx[s]; continue; }
+    uint64_t bits = 0;
+    for (int j = 0; j < n_meas; ++j) bits |= ((idx[s] >> meas_qubits[j]) & 1ull) << j;
+    out_bits[s] = bits;
+  }
+  return QSV_OK;
+}
+
+extern "C" int qsv_probabilities_cond(qsv_handle* h, const int* qubits, int k, uint64_t fix_mask, uint64_t fix_val,
+                                      double* out) {
+  if (!h || !out || (k && !qubits)) return fail(QSV_E_BADARG, "NULL argument");
+  if (k < 0 || k > 26) return fail(QSV_E_BADARG, "marginal over %d qubits unsupported (max 26)", k);
+  for (int i = 0; i < k; ++i) CHK(check_qubit(h, qubits[i], "marginal"));
+  const int ntab = 1 << k;
+  BitList bl;
+  bl.n = k;
+  for (int b = 0; b < k; ++b) bl.pos[b] = qubits[b];
+  std::vector<double> part(ntab);
+  for (int i = 0; i < ntab; ++i) out[i] = 0.0;
+  const uint64_t n = amps_local(h);
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    double* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, ntab * sizeof(double)));
+    HIPCHK(hipMemsetAsync(d_out, 0, ntab * sizeof(double), s.stream));
+    const uint64_t hi = (uint64_t)s.index << h->L;
+    const bool lds = k <= 12;
+    CHK(launch(h, s, QSV_K_PROB, 16.0 * (double)n, [&] {
+      const dim3 g(grid_for(h, s, n, QSV_TPB * 8));
+      if (lds) hipLaunchKernelGGL((k_marginal<true>), g, dim3(QSV_TPB), ntab * sizeof(double), s.stream, s.amp, n, hi, bl, fix_mask, fix_val, d_out, ntab);
+      else     hipLaunchKernelGGL((k_marginal<false>), g, dim3(QSV_TPB), 0, s.stream, s.amp, n, hi, bl, fix_mask, fix_val, d_out, ntab);
+    }));
+    HIPCHK(hipMemcpyAsync(part.data(), d_out, ntab * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipFree(d_out));
+    for (int i = 0; i < ntab; ++i) out[i] += part[i];
+  }
+  return QSV_OK;
+}
+extern "C" int qsv_probabilities(qsv_handle* h, const int* qubits, int k, double* out) {
+  return qsv_probabilities_cond(h, qubits, k, 0ull, 0ull, out);
+}
+
+static int amp_copy(qsv_handle* h, uint64_t start, uint64_t count, double* out, const double* in) {
+  if (!h || (count && !out && !in)) return fail(QSV_E_BADARG, "NULL argument");
+  const uint64_t n = amps_local(h);
+  uint64_t done = 0;
+  while (done < count) {
+    const uint64_t g = start + done;
+    const int si = (int)(g >> h->L);
+    Shard* sh = nullptr;
+    for (Shard& s : h->shards) if (s.index == si) sh = &s;
+    if (!sh) return fail(QSV_E_BADARG, "amplitude %llu lives on shard %d, which this process does not own", (unsigned long long)g, si);
+    const uint64_t off = g & (n - 1);
+    const uint64_t m = std::min(count - done, n - off);
+    CHK(shard_set(*sh));
+    HIPCHK(hipStreamSynchronize(sh->stream));
+    if (out) HIPCHK(hipMemcpy(out + 2 * done, sh->amp + off, m * sizeof(cplx), hipMemcpyDeviceToHost));
+    else     HIPCHK(hipMemcpy(sh->amp + off, in + 2 * done, m * sizeof(cplx), hipMemcpyHostToDevice));
+    done += m;
+  }
+  return QSV_OK;
+}
+extern "C" int qsv_get_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, double* out) { return amp_copy(h, start, count, out, nullptr); }
+extern "C" int qsv_set_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, const double* in) { return amp_copy(h, start, count, nullptr, in); }
+
+// ------------------------------------------------------------------------------------------
+// batched execution
+// ------------------------------------------------------------------------------------------
+extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const double* data, uint64_t n_data) {
+  if (!h || (n_ops && !ops)) return fail(QSV_E_BADARG, "NULL argument");
+  for (int i = 0; i < n_ops; ++i) {
+    const qsv_op& o = ops[i];
+    if (o.n < 0 || o.n > QSV_MAX_CTRL) return fail(QSV_E_BADARG, "op %d: n=%d out of range", i, o.n);
+    const double* d = data ? data + o.data_off : nullptr;
+    auto need = [&](uint64_t cnt) -> int {
+      if (!data || o.data_off + cnt > n_data) return fail(QSV_E_BADARG, "op %d: data range [%llu,+%llu) outside pool of %llu", i,
+                                                          (unsigned long long)o.data_off, (unsigned long long)cnt, (unsigned long long)n_data);
+      return QSV_OK;
+    };
+    int r = QSV_OK;
+    switch (o.kind) {
+      case QSV_OP_INIT_ZERO: r = qsv_init_zero(h); break;
+      case QSV_OP_INIT_UNIFORM: r = qsv_init_uniform(h, o.mask); break;
+      case QSV_OP_1Q: r = need(8); if (!r) r = apply_mc1q(h, o.n, o.qubits, o.vals, o.target, d, false); break;
+      case QSV_OP_MCX: r = apply_mc1q(h, o.n, o.qubits, o.vals, o.target, nullptr, true); break;
+      case QSV_OP_DIAG: r = need(2ull << o.n); if (!r) r = qsv_apply_diag(h, o.n, o.qubits, d); break;
+      case QSV_OP_MCPHASE: r = qsv_apply_mcphase(h, o.n, o.qubits, o.vals, o.angle); break;
+      case QSV_OP_MUX: r = need(8ull << o.n); if (!r) r = qsv_apply_mux_1q(h, o.n, o.qubits, o.target, d); break;
+      case QSV_OP_KQ: r = need(2ull << (2 * o.n)); if (!r) r = qsv_apply_kq(h, o.n, o.qubits, d); break;
+      case QSV_OP_SWAP: r = qsv_swap_layout(h, o.n, o.qubits, o.vals); break;
+      default: r = fail(QSV_E_BADARG, "op %d: unknown kind %d", i, o.kind);
+    }
+    if (r != QSV_OK) return r;
+  }
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// instrumentation
+// ------------------------------------------------------------------------------------------
+extern "C" int qsv_set_profiling(qsv_handle* h, int on) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  if (!on) CHK(drain_pending(h));
+  h->profiling = on != 0;
+  return QSV_OK;
+}
+extern "C" int qsv_reset_stats(qsv_handle* h) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  CHK(drain_pending(h));
+  memset(&h->stats, 0, sizeof h->stats);
+  return QSV_OK;
+}
+extern "C" int qsv_get_stats(qsv_handle* h, qsv_stats* out) {
+  if (!h || !out) return fail(QSV_E_BADARG, "NULL argument");
+  CHK(qsv_sync(h));
+  CHK(drain_pending(h));
+  *out = h->stats;
+  return QSV_OK;
+}
+extern "C" int qsv_timer_begin(qsv_handle* h) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  Shard& s = h->shards[0];
+  CHK(shard_set(s));
+  if (!h->t0) { HIPCHK(hipEventCreate(&h->t0)); HIPCHK(hipEventCreate(&h->t1)); }
+  HIPCHK(hipEventRecord(h->t0, s.stream));
+  return QSV_OK;
+}
+extern "C" int qsv_timer_end(qsv_handle* h, double* ms) {
+  if (!h || !ms || !h->t0) return fail(QSV_E_BADARG, "timer not started");
+  Shard& s = h->shards[0];
+  CHK(shard_set(s));
+  HIPCHK(hipEventRecord(h->t1, s.stream));
+  HIPCHK(hipEventSynchronize(h->t1));
+  float f = 0.f;
+  HIPCHK(hipEventElapsedTime(&f, h->t0, h->t1));
+  *ms = f;
+  return QSV_OK;
+}
+extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
+  if (!h || !name) return fail(QSV_E_BADARG, "NULL argument");
+  if (!strcmp(name, "blocks_per_cu")) { if (value < 1) return fail(QSV_E_BADARG, "blocks_per_cu < 1"); h->opt_blocks_per_cu = value; }
+  else if (!strcmp(name, "unroll")) h->opt_unroll = value;
+  else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
+  else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "exchange_chunk_log2")) { if (value < 4 || value > 32) return fail(QSV_E_BADARG, "exchange_chunk_log2 out of range"); h->opt_xchunk = 1ull << value; }
+  else return fail(QSV_E_BADARG, "unknown option %s", name);
+  return QSV_OK;
+}
+extern "C" const char* qsv_last_error(void) { return g_err.c_str(); }
+extern "C" const char* qsv_version(void) { return "qsv 0.1 (gfx950)"; }

@@ -1,0 +1,422 @@
+// qsv_kernels.h -- gfx950 (CDNA4, wave64) device kernels of the fp64 statevector engine.
+//
+// Every gate is a sweep over a shard of 2^L complex128 amplitudes resident in HBM; the
+// kernels are bandwidth kernels (0.44 flop/B for a 2x2) and are written for coalesced
+// 16-byte-per-lane (global_load_dwordx4) streams: one wave instruction = 1 KiB.
+//
+// Roofline per kernel (algorithmic bytes):
+//   k_pair / k_lowt / k_mux / k_diag / k_kq : 32 B per amplitude touched  (HBM bound)
+//   k_mcphase                               : 32 B per amplitude of the controlled subspace
+//   k_init                                  : 16 B per amplitude (write only)
+//   k_blocksum                              : 16 B per amplitude (read only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QSV_TPB 256
+#define QSV_MAXB 28          // >= QSV_MAX_CTRL + 1 insert positions; marginals gather up to 26 bits
+
+typedef double2 cplx;
+
+struct BitIns {              // sorted ascending bit positions at which a zero bit is inserted
+  int n;
+  int pos[QSV_MAXB];
+};
+struct BitList {             // gather list: result bit b <- index bit pos[b]
+  int n;
+  int pos[QSV_MAXB];
+};
+struct Mat2 { double v[8]; };  // row-major {re,im}: m00 m01 m10 m11
+
+__device__ __forceinline__ uint64_t ins_bits(uint64_t x, const BitIns& b) {
+  for (int j = 0; j < b.n; ++j) {
+    const int p = b.pos[j];
+    const uint64_t lo = x & ((1ull << p) - 1ull);
+    x = ((x >> p) << (p + 1)) | lo;
+  }
+  return x;
+}
+__device__ __forceinline__ uint32_t gather_bits(uint64_t x, const BitList& b) {
+  uint32_t j = 0;
+  for (int k = 0; k < b.n; ++k) j |= (uint32_t)((x >> b.pos[k]) & 1ull) << k;
+  return j;
+}
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cmad(cplx a, cplx b, cplx c) {   // a*b + c
+  return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+__device__ __forceinline__ cplx ld(const cplx* p) { return *p; }
+__device__ __forceinline__ void st(cplx* p, cplx v) { *p = v; }
+__device__ __forceinline__ cplx ld_nt(const cplx* p) {
+  return make_double2(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y));
+}
+__device__ __forceinline__ void st_nt(cplx* p, cplx v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+}
+
+// ---------------------------------------------------------------------------------------
+// state preparation
+// ---------------------------------------------------------------------------------------
+// amp[i] = ((i & nonmask) == 0) ? val : 0     (nonmask = ~uniform_mask over the local bits)
+__global__ __launch_bounds__(QSV_TPB) void k_init(cplx* __restrict__ amp, uint64_t n,
+                                                  uint64_t nonmask, double val) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t i = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; i < n; i += stride)
+    amp[i] = make_double2(((i & nonmask) == 0) ? val : 0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------
+// (multi-controlled) 2x2 on a target bit: one thread per amplitude pair, U pairs in flight.
+// ins = sorted {target, controls}; fixed = OR of control bits that must be 1.
+// For target >= 6 every wave instruction is a contiguous 1 KiB on both streams.
+// KIND 0: dense 2x2.  KIND 1: X (pure swap, no arithmetic).
+// ---------------------------------------------------------------------------------------
+template <int KIND, int U, bool GUARD, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64_t npairs,
+                                                  BitIns ins, uint64_t fixed, uint64_t tbit,
+                                                  Mat2 m) {
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  const cplx m00 = make_double2(m.v[0], m.v[1]), m01 = make_double2(m.v[2], m.v[3]);
+  const cplx m10 = make_double2(m.v[4], m.v[5]), m11 = make_double2(m.v[6], m.v[7]);
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < npairs;
+       base += stride) {
+    uint64_t i0[U];
+    cplx a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < npairs) {
+        i0[u] = ins_bits(p, ins) | fixed;
+        a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
+        a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < npairs) {
+        cplx r0, r1;
+        if (KIND == 1) { r0 = a1[u]; r1 = a0[u]; }
+        else {
+          r0 = cmad(m01, a1[u], cmul(m00, a0[u]));
+          r1 = cmad(m11, a1[u], cmul(m10, a0[u]));
+        }
+        if (NT) { st_nt(amp + i0[u], r0); st_nt(amp + (i0[u] | tbit), r1); }
+        else    { st(amp + i0[u], r0);    st(amp + (i0[u] | tbit), r1); }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// uncontrolled dense 2x2 on a LOW target bit (t < 6): the partner amplitude sits in another
+// lane of the same wavefront.  Each lane streams its own amplitudes (fully coalesced 1 KiB
+// per wave instruction) and fetches the partner with a wave shuffle (lane ^ (1<<t)).
+// Requires n % (QSV_TPB*U) == 0.
+// ---------------------------------------------------------------------------------------
+template <int U, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_lowt(cplx* __restrict__ amp, uint64_t n, int t,
+                                                  Mat2 m) {
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  const int b = (threadIdx.x >> t) & 1;
+  // row b of the matrix: out = diag * own + off * partner
+  const cplx dg = b ? make_double2(m.v[6], m.v[7]) : make_double2(m.v[0], m.v[1]);
+  const cplx of = b ? make_double2(m.v[4], m.v[5]) : make_double2(m.v[2], m.v[3]);
+  const int lm = 1 << t;
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n;
+       base += stride) {
+    cplx a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      a[u] = NT ? ld_nt(amp + base + (uint64_t)u * QSV_TPB) : ld(amp + base + (uint64_t)u * QSV_TPB);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cplx o;
+      o.x = __shfl_xor(a[u].x, lm, 64);
+      o.y = __shfl_xor(a[u].y, lm, 64);
+      const cplx r = cmad(of, o, cmul(dg, a[u]));
+      if (NT) st_nt(amp + base + (uint64_t)u * QSV_TPB, r);
+      else    st(amp + base + (uint64_t)u * QSV_TPB, r);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// uniformly controlled 2x2 ("multiplexed 1q"): mats[j], j = control bits of the pair index.
+// Table (2^k x 64 B) staged once per workgroup into LDS.
+// ---------------------------------------------------------------------------------------
+template <int U, bool GUARD, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_mux(cplx* __restrict__ amp, uint64_t npairs,
+                                                 int t, BitList ctl,
+                                                 const double* __restrict__ mats, int nmat) {
+  extern __shared__ double4 lds_mats[];   // nmat x 2 double4 = {m00,m01},{m10,m11}
+  {
+    const double4* src = reinterpret_cast<const double4*>(mats);
+    for (int i = threadIdx.x; i < nmat * 2; i += QSV_TPB) lds_mats[i] = src[i];
+  }
+  __syncthreads();
+  const uint64_t tbit = 1ull << t;
+  const uint64_t lomask = tbit - 1ull;
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < npairs;
+       base += stride) {
+    uint64_t i0[U];
+    cplx a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < npairs) {
+        i0[u] = ((p >> t) << (t + 1)) | (p & lomask);
+        a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
+        a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < npairs) {
+        const uint32_t j = gather_bits(i0[u], ctl);
+        const double4 r0m = lds_mats[2 * j], r1m = lds_mats[2 * j + 1];
+        const cplx m00 = make_double2(r0m.x, r0m.y), m01 = make_double2(r0m.z, r0m.w);
+        const cplx m10 = make_double2(r1m.x, r1m.y), m11 = make_double2(r1m.z, r1m.w);
+        const cplx r0 = cmad(m01, a1[u], cmul(m00, a0[u]));
+        const cplx r1 = cmad(m11, a1[u], cmul(m10, a0[u]));
+        if (NT) { st_nt(amp + i0[u], r0); st_nt(amp + (i0[u] | tbit), r1); }
+        else    { st(amp + i0[u], r0);    st(amp + (i0[u] | tbit), r1); }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k-qubit diagonal: amp[i] *= table[gather(i)].  LDS = true: table staged in LDS (k <= 11);
+// otherwise read through L2 from global memory.
+// ---------------------------------------------------------------------------------------
+template <int U, bool GUARD, bool LDS, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_diag(cplx* __restrict__ amp, uint64_t n,
+                                                  BitList q, const cplx* __restrict__ table,
+                                                  int ntab) {
+  extern __shared__ double4 lds_raw[];
+  cplx* lt = reinterpret_cast<cplx*>(lds_raw);
+  if (LDS) {
+    for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = table[i];
+    __syncthreads();
+  }
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n;
+       base += stride) {
+    cplx a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || i < n) a[u] = NT ? ld_nt(amp + i) : ld(amp + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || i < n) {
+        const uint32_t j = gather_bits(i, q);
+        const cplx d = LDS ? lt[j] : table[j];
+        const cplx r = cmul(a[u], d);
+        if (NT) st_nt(amp + i, r); else st(amp + i, r);
+      }
+    }
+  }
+}
+
+// phase on the control-satisfied subspace only: i = ins(p) | fixed, p < 2^(L - n_ctrl)
+template <int U, bool GUARD>
+__global__ __launch_bounds__(QSV_TPB) void k_mcphase(cplx* __restrict__ amp, uint64_t nsub,
+                                                     BitIns ins, uint64_t fixed, cplx ph) {
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < nsub;
+       base += stride) {
+    uint64_t idx[U];
+    cplx a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < nsub) { idx[u] = ins_bits(p, ins) | fixed; a[u] = amp[idx[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t p = base + (uint64_t)u * QSV_TPB;
+      if (!GUARD || p < nsub) amp[idx[u]] = cmul(a[u], ph);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// dense 2^K x 2^K unitary, one thread per group of 2^K amplitudes (registers), matrix in LDS.
+// First correct version; the MFMA f64 tile kernel replaces it for K >= 3 on contiguous tiles.
+// ---------------------------------------------------------------------------------------
+struct KqOffs { uint64_t off[32]; };
+template <int K>
+__global__ __launch_bounds__(QSV_TPB) void k_kq(cplx* __restrict__ amp, uint64_t ngroups,
+                                                BitIns ins, KqOffs offs,
+                                                const cplx* __restrict__ umat) {
+  constexpr int D = 1 << K;
+  extern __shared__ double4 lds_raw[];
+  cplx* lu = reinterpret_cast<cplx*>(lds_raw);
+  for (int i = threadIdx.x; i < D * D; i += QSV_TPB) lu[i] = umat[i];
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t g = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; g < ngroups; g += stride) {
+    const uint64_t base = ins_bits(g, ins);
+    cplx in[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) in[c] = amp[base | offs.off[c]];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      cplx acc = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc = cmad(lu[r * D + c], in[c], acc);
+      amp[base | offs.off[r]] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// layout: swap two local bit positions (a < b): amp[..1_a..0_b..] <-> amp[..0_a..1_b..]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(QSV_TPB) void k_swap_bits(cplx* __restrict__ amp, uint64_t nq,
+                                                       BitIns ins, uint64_t abit, uint64_t bbit) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t p = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; p < nq; p += stride) {
+    const uint64_t i = ins_bits(p, ins);
+    const cplx x = amp[i | abit], y = amp[i | bbit];
+    amp[i | abit] = y;
+    amp[i | bbit] = x;
+  }
+}
+
+// shard-bit <-> local-bit j exchange between two shards resident on ONE device:
+// A is the shard whose shard bit is 0, B the one whose shard bit is 1.
+__global__ __launch_bounds__(QSV_TPB) void k_swap_shards(cplx* __restrict__ A, cplx* __restrict__ B,
+                                                         uint64_t nhalf, int j) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  const uint64_t jbit = 1ull << j, lo = jbit - 1ull;
+  for (uint64_t p = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; p < nhalf; p += stride) {
+    const uint64_t i = ((p >> j) << (j + 1)) | (p & lo);
+    const cplx x = A[i | jbit], y = B[i];
+    A[i | jbit] = y;
+    B[i] = x;
+  }
+}
+
+// pack / unpack the half of a shard whose bit j equals v into / from a contiguous buffer
+// (chunk [p0, p0+cnt) of the 2^(L-1) half-space) -- staging for peer copies and RCCL.
+__global__ __launch_bounds__(QSV_TPB) void k_pack(const cplx* __restrict__ amp, cplx* __restrict__ buf,
+                                                  uint64_t p0, uint64_t cnt, int j, int v) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  const uint64_t jbit = 1ull << j, lo = jbit - 1ull;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
+    const uint64_t p = p0 + q;
+    buf[q] = amp[((p >> j) << (j + 1)) | (p & lo) | (v ? jbit : 0ull)];
+  }
+}
+__global__ __launch_bounds__(QSV_TPB) void k_unpack(cplx* __restrict__ amp, const cplx* __restrict__ buf,
+                                                    uint64_t p0, uint64_t cnt, int j, int v) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  const uint64_t jbit = 1ull << j, lo = jbit - 1ull;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
+    const uint64_t p = p0 + q;
+    amp[((p >> j) << (j + 1)) | (p & lo) | (v ? jbit : 0ull)] = buf[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------
+#define QSV_SBLOCK 4096      // amplitudes per sampling block (64 KiB)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sums[b] = sum |amp|^2 over block b (fixed-order tree: deterministic)
+__global__ __launch_bounds__(QSV_TPB) void k_blocksum(const cplx* __restrict__ amp, uint64_t n,
+                                                      double* __restrict__ sums, uint64_t nblocks) {
+  __shared__ double part[QSV_TPB / 64];
+  for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const uint64_t lo = b * QSV_SBLOCK;
+    double s = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < QSV_SBLOCK / QSV_TPB; ++k) {
+      const uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
+      if (i < n) { const cplx a = amp[i]; s = fma(a.x, a.x, fma(a.y, a.y, s)); }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[b] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+  }
+}
+
+// one wave per shot: find the first index in block blk[s] whose running |amp|^2 sum exceeds
+// resid[s]; rows of 64 amplitudes are scanned with a wave prefix sum.
+__global__ __launch_bounds__(64) void k_locate(const cplx* __restrict__ amp, uint64_t n,
+                                               const uint64_t* __restrict__ blk,
+                                               const double* __restrict__ resid,
+                                               uint64_t* __restrict__ out, uint64_t shots) {
+  const int lane = threadIdx.x;
+  for (uint64_t s = blockIdx.x; s < shots; s += gridDim.x) {
+    const uint64_t lo = blk[s] * QSV_SBLOCK;
+    const double r = resid[s];
+    double run = 0.0;
+    uint64_t found = ~0ull, last_nz = lo;
+    for (int row = 0; row < QSV_SBLOCK / 64 && found == ~0ull; ++row) {
+      const uint64_t i = lo + (uint64_t)row * 64 + lane;
+      double p = 0.0;
+      if (i < n) { const cplx a = amp[i]; p = fma(a.x, a.x, a.y * a.y); }
+      double inc = p;                       // inclusive wave scan
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      const unsigned long long hit = __ballot(p > 0.0 && run + inc > r);
+      const unsigned long long nz = __ballot(p > 0.0);
+      if (hit) found = lo + (uint64_t)row * 64 + (uint64_t)__builtin_ctzll(hit);
+      if (nz) last_nz = lo + (uint64_t)row * 64 + (uint64_t)(63 - __builtin_clzll(nz));
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) out[s] = (found == ~0ull) ? last_nz : found;   // rounding slack -> last nonzero
+  }
+}
+
+// marginal over up to 26 qubits; only indices with (g & fmask) == fval contribute, where
+// g = hi | i is the global index.  Small tables are pre-reduced in LDS.
+template <bool LDS>
+__global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ amp, uint64_t n,
+                                                      uint64_t hi, BitList q, uint64_t fmask,
+                                                      uint64_t fval, double* __restrict__ out,
+                                                      int ntab) {
+  extern __shared__ double lds_acc[];
+  if (LDS) {
+    for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lds_acc[i] = 0.0;
+    __syncthreads();
+  }
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t i = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; i < n; i += stride) {
+    const uint64_t g = hi | i;
+    if ((g & fmask) != fval) continue;
+    const cplx a = amp[i];
+    const double p = fma(a.x, a.x, a.y * a.y);
+    if (p != 0.0) {
+      const uint32_t j = gather_bits(g, q);
+      if (LDS) atomicAdd(&lds_acc[j], p); else atomicAdd(&out[j], p);
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += QSV_TPB)
+      if (lds_acc[i] != 0.0) atomicAdd(&out[i], lds_acc[i]);
+  }
+}

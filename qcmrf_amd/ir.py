@@ -1,0 +1,146 @@
+"""Gate-level intermediate representation the engine executes.
+
+Qubits are LOGICAL until ``planner.plan`` maps them onto physical amplitude-index positions.
+Little-endian throughout: qubit q is bit q of the basis index (Qiskit convention).
+
+kinds
+-----
+init     mask                       |0..0> with H on every qubit of ``mask`` (written directly)
+u        target, ctrls, vals, mat   (multi-controlled) dense 2x2
+x        target, ctrls, vals        (multi-controlled) X: pure permutation
+diag     qubits, table              table[j], j = sum_b bit(qubits[b]) << b
+mcphase  qubits, vals, angle        e^{i angle} where every qubit matches its value
+mux      ctrls, target, mats        uniformly controlled 2x2, mats[j] with j from ctrls (LSB first)
+kq       qubits, mat                dense 2^k x 2^k, index bit b <-> qubits[b]
+swap     a, b                       physical layout swap (planner output only)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SQ2 = 1.0 / np.sqrt(2.0)
+
+
+def _m(rows):
+    return np.array(rows, dtype=np.complex128)
+
+
+FIXED_1Q = {
+    "h": _m([[SQ2, SQ2], [SQ2, -SQ2]]),
+    "y": _m([[0, -1j], [1j, 0]]),
+    "sx": 0.5 * _m([[1 + 1j, 1 - 1j], [1 - 1j, 1 + 1j]]),
+    "sxdg": 0.5 * _m([[1 - 1j, 1 + 1j], [1 + 1j, 1 - 1j]]),
+}
+FIXED_PHASE = {          # diag(1, e^{i lam})
+    "z": np.pi, "s": np.pi / 2, "sdg": -np.pi / 2, "t": np.pi / 4, "tdg": -np.pi / 4,
+}
+
+
+def rx(th):
+    c, s = np.cos(th / 2), np.sin(th / 2)
+    return _m([[c, -1j * s], [-1j * s, c]])
+
+
+def ry(th):
+    c, s = np.cos(th / 2), np.sin(th / 2)
+    return _m([[c, -s], [s, c]])
+
+
+def u3(th, ph, lam):
+    c, s = np.cos(th / 2), np.sin(th / 2)
+    return _m([[c, -np.exp(1j * lam) * s], [np.exp(1j * ph) * s, np.exp(1j * (ph + lam)) * c]])
+
+
+class Op:
+    __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
+                 "a", "b", "label")
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.target = None
+        self.ctrls, self.vals, self.qubits = (), (), ()
+        self.mat = self.table = self.mats = None
+        self.angle = 0.0
+        self.mask = 0
+        self.a = self.b = ()
+        self.label = ""
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def support(self):
+        """every logical qubit the op reads or writes"""
+        if self.kind in ("u", "x"):
+            return tuple(self.ctrls) + (self.target,)
+        if self.kind == "mux":
+            return tuple(self.ctrls) + (self.target,)
+        if self.kind in ("diag", "mcphase", "kq"):
+            return tuple(self.qubits)
+        if self.kind == "swap":
+            return tuple(self.a) + tuple(self.b)
+        return ()
+
+    def dense_targets(self):
+        """qubits on which the op is NOT diagonal (these must be local to a shard)"""
+        if self.kind in ("u", "x", "mux"):
+            return (self.target,)
+        if self.kind == "kq":
+            return tuple(self.qubits)
+        return ()
+
+    def __repr__(self):
+        if self.kind in ("u", "x"):
+            return "%s(t=%s, c=%s%s)" % (self.kind if not self.label else self.label, self.target,
+                                        list(self.ctrls), "" if all(self.vals) else " v=%s" % list(self.vals))
+        if self.kind == "mux":
+            return "mux(t=%s, c=%s)" % (self.target, list(self.ctrls))
+        if self.kind == "diag":
+            return "diag(%s)" % (list(self.qubits),)
+        if self.kind == "mcphase":
+            return "mcphase(%s, %.6g)" % (list(self.qubits), self.angle)
+        if self.kind == "kq":
+            return "kq(%s)" % (list(self.qubits),)
+        if self.kind == "init":
+            return "init(mask=%#x)" % self.mask
+        if self.kind == "swap":
+            return "swap(%s,%s)" % (list(self.a), list(self.b))
+        return self.kind
+
+
+def op_u(target, mat, ctrls=(), vals=None, label=""):
+    vals = tuple(1 for _ in ctrls) if vals is None else tuple(int(v) for v in vals)
+    return Op("u", target=int(target), mat=np.asarray(mat, dtype=np.complex128).reshape(2, 2),
+              ctrls=tuple(int(c) for c in ctrls), vals=vals, label=label)
+
+
+def op_x(target, ctrls=(), vals=None):
+    vals = tuple(1 for _ in ctrls) if vals is None else tuple(int(v) for v in vals)
+    return Op("x", target=int(target), ctrls=tuple(int(c) for c in ctrls), vals=vals)
+
+
+def op_diag(qubits, table):
+    return Op("diag", qubits=tuple(int(q) for q in qubits),
+              table=np.asarray(table, dtype=np.complex128).ravel())
+
+
+def op_phase1(qubit, lam):
+    return op_diag([qubit], [1.0, np.exp(1j * lam)])
+
+
+def op_mcphase(qubits, angle, vals=None):
+    vals = tuple(1 for _ in qubits) if vals is None else tuple(int(v) for v in vals)
+    return Op("mcphase", qubits=tuple(int(q) for q in qubits), vals=vals, angle=float(angle))
+
+
+def op_mux(ctrls, target, mats):
+    return Op("mux", ctrls=tuple(int(c) for c in ctrls), target=int(target),
+              mats=np.asarray(mats, dtype=np.complex128).reshape(-1, 2, 2))
+
+
+def op_kq(qubits, mat):
+    k = len(qubits)
+    return Op("kq", qubits=tuple(int(q) for q in qubits),
+              mat=np.asarray(mat, dtype=np.complex128).reshape(2 ** k, 2 ** k))
+
+
+def op_init(mask):
+    return Op("init", mask=int(mask))

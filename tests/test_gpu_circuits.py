@@ -1,0 +1,192 @@
+"""GPU parity of whole QCMRF circuits: engine (through the C ABI) vs the oracle.
+
+Tolerances: amplitudes 1e-12 absolute, probabilities 1e-10 (the bar BASELINE.json states for
+fp64); counts are compared statistically (Aer's own committed counts are unseeded samples)."""
+import numpy as np
+import pytest
+
+from conftest import random_theta
+from oracle import closed_form as cf, gate_stream as gs, sv_numpy as sv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from qcmrf_amd.backend import QsvBackend
+    b = QsvBackend()
+    yield b
+    b.close()
+
+
+def logical_index(layout, n_qubits):
+    p = np.arange(2 ** n_qubits, dtype=np.uint64)
+    l = np.zeros_like(p)
+    for q, pos in enumerate(layout):
+        l |= ((p >> np.uint64(pos)) & np.uint64(1)) << np.uint64(q)
+    return l
+
+
+def run_state(be, qc, **opts):
+    """evolve only (shots=0) and return amplitudes in LOGICAL index order + metadata"""
+    res = be.run(qc, shots=0, **opts).result()
+    meta = res.metadata(0)
+    amp = be.last_engine.amplitudes()
+    l = logical_index(meta["layout"], meta["n_qubits"]).astype(np.int64)
+    out = np.empty_like(amp)
+    out[l] = amp
+    return out, meta
+
+
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+def test_reference_graphs_amplitudes(be, models, fusion):
+    from qcmrf_amd import QCMRF
+    for s in ("0.1", "0.5"):
+        for j, C in enumerate(models[s]["GRAPHS"]):
+            for rep in (0, 7):
+                th = models[s]["THETAS"][str(j)][rep]
+                amp, meta = run_state(be, QCMRF(C, th), fusion=fusion)
+                want = cf.amplitudes(C, th)
+                assert np.abs(amp - want).max() < 1e-12
+                assert np.abs(np.abs(amp) ** 2 - cf.probabilities(C, th)).max() < 1e-10
+
+
+def test_config1_golden_vector(be, config1):
+    from qcmrf_amd import QCMRF
+    amp, _ = run_state(be, QCMRF(config1["cliques"], config1["theta"]))
+    want = np.array(config1["amp_re"]) + 1j * np.array(config1["amp_im"])
+    assert np.abs(amp - want).max() < 1e-12
+    assert np.abs(np.abs(amp) ** 2 - np.array(config1["probabilities"])).max() < 1e-10
+
+
+def test_exec_and_stepwise_agree_with_gate_level_oracle(be):
+    """fusion 0 = the reference's own gate stream, gate by gate; checked against the numpy
+    gate-level simulator (not the closed form) at W = 14."""
+    from qcmrf_amd import QCMRF, _lib, program
+    C = gs.chain_cliques(7)
+    th = random_theta(cf.model_shape(C)[3])
+    qc = QCMRF(C, th)
+    W = qc.num_qubits
+    want = sv.run_stream(gs.reference_stream(C, th), W)
+    amp, meta = run_state(be, qc, fusion=0)
+    assert meta["n_device_ops"] == meta["n_source_ops"] - (W - 1) + 1     # every gate, + init, - measures
+    assert np.abs(amp - want).max() < 1e-12
+    ing, pl = be.compile(qc, fusion=0)
+    with _lib.Engine(W) as e:
+        program.run_stepwise(e, pl.ops)
+        assert np.abs(e.amplitudes() - want).max() < 1e-12
+
+
+@pytest.mark.parametrize("fusion", [0, 2])
+def test_config2_chain_w20(be, fusion):
+    from qcmrf_amd import QCMRF
+    C = gs.chain_cliques(10)
+    th = random_theta(36)
+    amp, meta = run_state(be, QCMRF(C, th), fusion=fusion)
+    assert meta["n_qubits"] == 20
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+
+
+@pytest.mark.parametrize("layout", ["auto", "reference"])
+@pytest.mark.parametrize("P", [2, 4, 8])
+@pytest.mark.parametrize("fusion", [0, 2])
+def test_virtual_shards_match_single_shard(be, P, layout, fusion):
+    """P shards on one device: shard-bit controls / table slicing / exchanges are the real
+    library code; only the transport (device copy instead of RCCL) differs from multi-GPU."""
+    from qcmrf_amd import QCMRF
+    C = gs.grid_cliques(2, 3)                      # n=6, m=7, W=14
+    th = random_theta(cf.model_shape(C)[3], seed=P)
+    amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, layout=layout, devices=(0,) * P)
+    assert meta["n_shards"] == P
+    if layout == "auto" and fusion == 2:
+        assert meta["n_exchanges"] == 0
+    if layout == "reference":
+        assert meta["n_exchanges"] > 0
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+
+
+def test_counts_vs_closed_form_and_vs_aer(be, models, aer_counts):
+    from qcmrf_amd import QCMRF
+    m = models["0.5"]
+    circs, dists = [], []
+    for j, C in enumerate(m["GRAPHS"]):
+        for rep in range(10):
+            circs.append(QCMRF(C, m["THETAS"][str(j)][rep]))
+            dists.append((C, m["THETAS"][str(j)][rep]))
+    counts = be.run(circs, shots=10000, seed_simulator=1984).result().get_counts()
+    assert isinstance(counts, list) and len(counts) == 70
+    chis, chis2 = [], []
+    for k, (C, th) in enumerate(dists):
+        n, mm, W, dim = cf.model_shape(C)
+        assert all(len(key) == W and isinstance(v, int) for key, v in counts[k].items())
+        assert sum(counts[k].values()) == 10000
+        p = cf.probabilities(C, th)
+        obs = np.zeros(2 ** W)
+        for key, v in counts[k].items():
+            obs[int(key, 2)] += v
+        assert obs[p == 0].sum() == 0                       # support, incl. classical bit n == '0'
+        sel = p * 10000 > 5
+        chis.append(((obs[sel] - p[sel] * 1e4) ** 2 / (p[sel] * 1e4)).sum() / max(sel.sum() - 1, 1))
+        aer = np.zeros(2 ** W)
+        for key, v in aer_counts["0.5"][k].items():
+            aer[int(key, 2)] += v
+        both = (obs + aer) > 10                             # two-sample chi^2 against Aer's own counts
+        chis2.append(((obs[both] - aer[both]) ** 2 / (obs[both] + aer[both])).sum() / max(both.sum() - 1, 1))
+    assert 0.85 < np.mean(chis) < 1.15
+    assert 0.85 < np.mean(chis2) < 1.15
+
+
+def test_extract_probs_pipeline(be, models):
+    """run_experiment.py + eval.py arithmetic end to end: fidelity with the exact Gibbs pmf."""
+    from qcmrf_amd import QCMRF, extract_probs, fidelity
+    C = models["0.5"]["GRAPHS"][3]
+    th = models["0.5"]["THETAS"]["3"][0]
+    qc = QCMRF(C, th)
+    counts = be.run(qc, shots=100000, seed_simulator=7).result().get_counts()
+    q, delta = extract_probs(counts, qc.num_vertices, qc.num_cliques + 1)
+    p, Z = cf.gibbs_pmf(C, th)
+    assert fidelity(p, q) > 0.999
+    assert abs(delta - Z / 2 ** qc.num_vertices) < 0.01
+
+
+def test_full_size_w28_properties(be):
+    """BASELINE config 3 (2x6 grid minus last edge, W = 28, 4 GiB state): size-independent checks.
+    norm = 1; P(all ancillas 0) = Z/2^n; P(x | ancillas 0) = Gibbs pmf (1e-10); random amplitude
+    slices equal the closed form (1e-12)."""
+    from qcmrf_amd import QCMRF
+    C = gs.grid_cliques(2, 6, drop_last=1)
+    n, m, W, dim = cf.model_shape(C)
+    assert (n, m, W, dim) == (12, 15, 28, 60)
+    th = random_theta(dim)
+    qc = QCMRF(C, th)
+    res = be.run(qc, shots=4096, seed_simulator=1984).result()
+    meta = res.metadata(0)
+    lay = meta["layout"]
+    eng = be.last_engine
+    assert abs(eng.norm() - 1.0) < 1e-12
+    # conditional distribution over the variable qubits given every other qubit reads 0
+    var_phys = [lay[q] for q in range(n)]
+    fix_mask = 0
+    for q in range(n, W):
+        fix_mask |= 1 << lay[q]
+    px = eng.probabilities(var_phys, fix_mask, 0)          # index bit q <-> variable qubit q
+    p, Z = cf.gibbs_pmf(C, th)                              # index has x_0 as MSB; variable v on qubit n-1-v
+    assert abs(px.sum() - Z / 2 ** n) < 1e-10
+    assert np.abs(px / px.sum() - p).max() < 1e-10
+    # amplitude slices
+    rs = np.random.RandomState(0)
+    linv = logical_index(lay, W) if W <= 20 else None
+    for start in rs.randint(0, 2 ** W - 4096, size=16).tolist() + [0, 2 ** W - 4096]:
+        got = eng.amplitudes(start, 4096)
+        pidx = np.arange(start, start + 4096, dtype=np.uint64)
+        lidx = np.zeros_like(pidx)
+        for q, pos in enumerate(lay):
+            lidx |= ((pidx >> np.uint64(pos)) & np.uint64(1)) << np.uint64(q)
+        assert np.abs(got - cf.amplitudes_at(C, th, lidx)).max() < 1e-12
+    # counts: only supported keys, success rate within sampling error
+    counts = res.get_counts()
+    assert sum(counts.values()) == 4096
+    ok = sum(v for k, v in counts.items() if int(k, 2) < 2 ** n)
+    delta = Z / 2 ** n
+    assert abs(ok / 4096 - delta) < 5 * np.sqrt(delta * (1 - delta) / 4096) + 1e-3
+    assert all(k[W - 1 - n] == "0" for k in counts)         # classical bit n is never written

@@ -1,0 +1,234 @@
+"""GPU parity: every HIP kernel against the numpy oracle on the same seeded state (bit-level
+index conventions + fp64 arithmetic; tolerance 1e-13 absolute on amplitudes of a unit vector)."""
+import numpy as np
+import pytest
+
+from oracle import sv_numpy as sv
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from qcmrf_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def rand_state(n, seed):
+    rs = np.random.RandomState(seed)
+    v = rs.randn(2 ** n) + 1j * rs.randn(2 ** n)
+    return v / np.linalg.norm(v)
+
+
+def rand_u(k, seed):
+    rs = np.random.RandomState(seed)
+    a = rs.randn(2 ** k, 2 ** k) + 1j * rs.randn(2 ** k, 2 ** k)
+    q, _ = np.linalg.qr(a)
+    return q
+
+
+@pytest.mark.parametrize("n", [3, 6, 9, 13, 16])
+def test_dense_1q_every_target(lib, n):
+    ref = rand_state(n, n)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        for t in range(n):
+            m = rand_u(1, 100 + t)
+            e.apply_1q(t, m)
+            sv.apply_1q(ref, t, m)
+        got = e.amplitudes()
+    assert np.abs(got - ref).max() < TOL
+
+
+@pytest.mark.parametrize("shuffle", [0, 1])
+def test_lowt_shuffle_matches_pair_kernel(lib, shuffle):
+    n = 14
+    ref = rand_state(n, 5)
+    with lib.Engine(n) as e:
+        e.set_option("lowt_shuffle", shuffle)
+        e.set_amplitudes(0, ref)
+        for t in range(6):
+            m = rand_u(1, t)
+            e.apply_1q(t, m)
+            sv.apply_1q(ref, t, m)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("n", [4, 10, 15])
+def test_controlled_1q_and_mcx_with_flags(lib, n):
+    rs = np.random.RandomState(n)
+    ref = rand_state(n, 7)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        for trial in range(24):
+            nc = rs.randint(0, min(4, n - 1) + 1)
+            qs = rs.permutation(n)[: nc + 1].tolist()
+            vals = rs.randint(0, 2, size=nc).tolist()
+            if trial % 2:
+                e.apply_mcx(qs[:-1], qs[-1], vals)
+                sv.apply_mcx(ref, qs[:-1], qs[-1], vals)
+            else:
+                m = rand_u(1, trial)
+                e.apply_1q(qs[-1], m, qs[:-1], vals)
+                sv.apply_1q(ref, qs[-1], m, qs[:-1], vals)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("n", [3, 9, 14])
+def test_diag_and_mcphase(lib, n):
+    rs = np.random.RandomState(n)
+    ref = rand_state(n, 11)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        for trial in range(12):
+            k = rs.randint(1, min(n, 6) + 1)
+            qs = rs.permutation(n)[:k].tolist()
+            tab = np.exp(1j * rs.uniform(-3, 3, size=2 ** k))
+            e.apply_diag(qs, tab)
+            sv.apply_diag(ref, qs, tab)
+            vals = rs.randint(0, 2, size=k).tolist()
+            ang = rs.uniform(-3, 3)
+            e.apply_mcphase(qs, ang, vals)
+            sv.apply_mcphase(ref, qs, ang, vals)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
+def test_diag_wide_table_global_path(lib):
+    n, k = 14, 13
+    rs = np.random.RandomState(3)
+    ref = rand_state(n, 1)
+    qs = rs.permutation(n)[:k].tolist()
+    tab = np.exp(1j * rs.uniform(-3, 3, size=2 ** k))
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        e.apply_diag(qs, tab)
+        sv.apply_diag(ref, qs, tab)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("n", [4, 9, 15])
+def test_mux(lib, n):
+    rs = np.random.RandomState(n)
+    ref = rand_state(n, 13)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        for trial in range(10):
+            k = rs.randint(0, min(n - 1, 5) + 1)
+            qs = rs.permutation(n)[: k + 1].tolist()
+            mats = np.array([rand_u(1, 1000 * trial + j) for j in range(2 ** k)])
+            e.apply_mux(qs[:-1], qs[-1], mats)
+            sv.apply_mux(ref, qs[:-1], qs[-1], mats)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("n,k", [(5, 1), (6, 2), (9, 3), (12, 4), (13, 5)])
+def test_kq_dense(lib, n, k):
+    rs = np.random.RandomState(n * 10 + k)
+    ref = rand_state(n, 17)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        for trial in range(4):
+            qs = rs.permutation(n)[:k].tolist()
+            u = rand_u(k, trial)
+            e.apply_kq(qs, u)
+            sv.apply_kq(ref, qs, u)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-12
+
+
+def test_init_uniform_and_zero(lib):
+    n = 11
+    with lib.Engine(n) as e:
+        e.init_zero()
+        a = e.amplitudes()
+        assert a[0] == 1 and np.count_nonzero(a) == 1
+        mask = 0b10110100101
+        e.init_uniform(mask)
+        a = e.amplitudes()
+        idx = np.arange(2 ** n)
+        want = np.where((idx & ~mask) == 0, 2.0 ** (-0.5 * bin(mask).count("1")), 0.0)
+        assert np.array_equal(a, want.astype(np.complex128))
+
+
+def test_swap_layout_local(lib):
+    n = 10
+    ref = rand_state(n, 19)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        e.swap_layout([1, 7], [8, 3])
+        got = e.amplitudes()
+    idx = np.arange(2 ** n)
+
+    def sw(i, a, b):
+        ba, bb = (i >> a) & 1, (i >> b) & 1
+        return (i & ~((1 << a) | (1 << b))) | (bb << a) | (ba << b)
+    want = ref[sw(sw(idx, 1, 8), 7, 3)]
+    assert np.array_equal(got, want)
+
+
+def test_probabilities_norm_and_conditional(lib):
+    n = 12
+    ref = rand_state(n, 23)
+    p = np.abs(ref) ** 2
+    idx = np.arange(2 ** n)
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        assert abs(e.norm() - 1.0) < 1e-13
+        qs = [9, 0, 4]
+        got = e.probabilities(qs)
+        j = ((idx >> 9) & 1) | (((idx >> 0) & 1) << 1) | (((idx >> 4) & 1) << 2)
+        want = np.bincount(j, weights=p, minlength=8)
+        assert np.abs(got - want).max() < 1e-13
+        fm, fv = (1 << 11) | (1 << 2), (1 << 2)
+        got = e.probabilities(qs, fm, fv)
+        sel = (idx & fm) == fv
+        want = np.bincount(j[sel], weights=p[sel], minlength=8)
+        assert np.abs(got - want).max() < 1e-13
+        full = e.probabilities(list(range(n)))
+        assert np.abs(full - p).max() < 1e-15
+
+
+def test_sampling_matches_distribution(lib):
+    n = 10
+    ref = rand_state(n, 29)
+    ref[(np.arange(2 ** n) & 0b1000) != 0] = 0          # a structurally empty half
+    ref /= np.linalg.norm(ref)
+    p = np.abs(ref) ** 2
+    shots = 200000
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        s1 = e.sample(shots, 1234)
+        s2 = e.sample(shots, 1234)
+        s3 = e.sample(shots, 99)
+    assert np.array_equal(s1, s2) and not np.array_equal(s1, s3)       # seeded, reproducible
+    cnt = np.bincount(s1.astype(np.int64), minlength=2 ** n)
+    assert cnt[p == 0].sum() == 0                                        # never outside the support
+    sel = p * shots > 5
+    chi2 = ((cnt[sel] - p[sel] * shots) ** 2 / (p[sel] * shots)).sum() / (sel.sum() - 1)
+    assert 0.8 < chi2 < 1.25
+    # measured-qubit packing
+    with lib.Engine(n) as e:
+        e.set_amplitudes(0, ref)
+        raw = e.sample(1000, 5)
+        packed = e.sample(1000, 5, [7, 1, 3])
+    want = ((raw >> 7) & 1) | (((raw >> 1) & 1) << 1) | (((raw >> 3) & 1) << 2)
+    assert np.array_equal(packed, want)
+
+
+def test_errors_are_loud(lib):
+    with lib.Engine(5) as e:
+        with pytest.raises(ValueError):
+            e.apply_1q(5, np.eye(2))
+        with pytest.raises(ValueError):
+            e.apply_mcx([1, 1], 2)
+        with pytest.raises(ValueError):
+            e.apply_mcx([2], 2)
+        with pytest.raises(ValueError):
+            e.init_uniform(1 << 5)
+    with pytest.raises(ValueError):
+        lib.Engine(5, devices=(0, 0, 0))            # not a power of two
+    with lib.Engine(6, devices=(0, 0)) as e:        # target on the shard bit must be refused
+        with pytest.raises(RuntimeError):
+            e.apply_1q(5, np.eye(2))

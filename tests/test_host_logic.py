@@ -1,0 +1,222 @@
+"""CPU: ingest, fusion passes, planner and program encoding, executed on the numpy stand-in
+engine (oracle/sharded_numpy.py) and checked against the closed form / the gate-level oracle."""
+import numpy as np
+import pytest
+
+from conftest import random_theta
+from oracle import closed_form as cf, gate_stream as gs, sv_numpy as sv
+from oracle.sharded_numpy import NumpyEngine
+from qcmrf_amd import QCMRF, ir, passes, planner, program, workloads
+from qcmrf_amd.backend import QsvBackend
+from qcmrf_amd.ingest import ingest
+
+
+def logical_amplitudes(eng, layout, W):
+    amp = eng.amplitudes()
+    p = np.arange(2 ** W, dtype=np.int64)
+    l = np.zeros_like(p)
+    for q, pos in enumerate(layout):
+        l |= ((p >> pos) & 1) << q
+    out = np.empty_like(amp)
+    out[l] = amp
+    return out
+
+
+def run_numpy(qc, fusion=2, shards=1, layout="auto"):
+    be = QsvBackend()
+    ing, pl = be.compile(qc, shards, fusion=fusion, layout=layout)
+    eng = NumpyEngine(ing.num_qubits, shards)
+    program.run_stepwise(eng, pl.ops)
+    return logical_amplitudes(eng, pl.layout, ing.num_qubits), ing, pl, eng
+
+
+def test_ingest_flattens_to_reference_stream(models):
+    """fusion 0: the ingested primitive list is the reference's gate stream, op for op"""
+    for j, C in enumerate(models["0.5"]["GRAPHS"]):
+        th = models["0.5"]["THETAS"][str(j)][3]
+        ing = ingest(QCMRF(C, th))
+        ref = [o for o in gs.reference_stream(C, th) if o[0] != "measure"]
+        assert len(ing.ops) == len(ref)
+        for op, r in zip(ing.ops, ref):
+            if r[0] == "h":
+                assert op.kind == "u" and op.target == r[1] and op.label == "h"
+            elif r[0] == "x":
+                assert op.kind == "x" and op.target == r[1] and not op.ctrls
+            elif r[0] == "mcx":
+                assert op.kind == "x" and op.ctrls == tuple(r[1]) and op.target == r[2] and all(op.vals)
+            elif r[0] == "cp":
+                assert op.kind == "mcphase" and op.qubits == (r[2], r[3]) and op.angle == r[1]
+        n, m, W, dim = cf.model_shape(C)
+        assert ing.measure == {**{n + 1 + i: n + 1 + i for i in range(m)}, **{q: q for q in range(n)}}
+        assert ing.num_clbits == W and n not in ing.measure
+
+
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+def test_fusion_levels_are_exact(models, fusion):
+    for j, C in enumerate(models["0.25"]["GRAPHS"]):
+        th = models["0.25"]["THETAS"][str(j)][1]
+        amp, ing, pl, _ = run_numpy(QCMRF(C, th), fusion=fusion)
+        assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-13
+
+
+def test_fused_program_shape():
+    C = workloads.grid(2, 6, drop_last=1)
+    qc = QCMRF(C, random_theta(60))
+    be = QsvBackend()
+    ing, pl = be.compile(qc, fusion=2)
+    kinds = [o.kind for o in pl.ops]
+    assert kinds == ["init"] + ["mux"] * 15                  # one sweep per clique
+    assert all(len(o.ctrls) == 3 for o in pl.ops[1:])       # two variables + the AND scratch qubit
+    ing, pl = be.compile(qc, fusion=1)
+    assert [o.kind for o in pl.ops] == ["init"] + ["diag", "u"] * 15
+    ing, pl = be.compile(qc, fusion=0)
+    assert len(pl.ops) == 1 + 12 + 15 * 60
+
+
+def test_gamma_close_to_zero_is_skipped():
+    C = [[0, 1], [1, 2]]
+    th = [0.0, -0.3, -1e-20, -0.7, -0.2, 0.0, -0.9, -0.4]
+    amp, ing, pl, _ = run_numpy(QCMRF(C, th), fusion=0)
+    n_cp = sum(1 for o in ing.ops if o.kind == "mcphase")
+    assert n_cp == 2 * 5                                      # three parameters emit no gates at all
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-13
+
+
+def test_with_barriers_and_without_measurements():
+    C = [[0, 1], [1, 2]]
+    th = random_theta(8)
+    a1, ing1, _, _ = run_numpy(QCMRF(C, th, with_barriers=True))
+    a2, ing2, _, _ = run_numpy(QCMRF(C, th, with_measurements=False))
+    assert np.abs(a1 - cf.amplitudes(C, th)).max() < 1e-13 and np.abs(a2 - a1).max() < 1e-15
+    assert ing2.measure == {}
+
+
+def rand_circuit(nq, n_ops, seed):
+    """random circuit over the engine's primitive set, as (container circuit, oracle stream)"""
+    from qcmrf_amd.circuit import QuantumCircuit
+    rs = np.random.RandomState(seed)
+    qc = QuantumCircuit(nq, nq)
+    for _ in range(n_ops):
+        k = rs.randint(0, 10)
+        q = rs.permutation(nq)[:3].tolist()
+        a = float(rs.uniform(-3, 3))
+        if k == 0: qc.h(q[0])
+        elif k == 1: qc.x(q[0])
+        elif k == 2: qc.cx(q[0], q[1])
+        elif k == 3: qc.ccx(q[0], q[1], q[2])
+        elif k == 4: qc.rz(a, q[0])
+        elif k == 5: qc.cp(a, q[0], q[1])
+        elif k == 6: qc.sx(q[0])
+        elif k == 7: qc.t(q[0]); qc.s(q[1]); qc.z(q[2])
+        elif k == 8: qc.cz(q[0], q[1]); qc.y(q[2])
+        else: qc.ry(a, q[0]); qc.swap(q[1], q[2])
+    return qc
+
+
+def oracle_state_of(qc):
+    """independent evaluation of a container circuit with the numpy oracle"""
+    s = sv.zero_state(qc.num_qubits)
+    for ci in qc.data:
+        name, p = ci.operation.name, ci.operation.params
+        q = [qc.find_bit(b).index for b in ci.qubits]
+        if name in sv.MATS: sv.apply_1q(s, q[0], sv.MATS[name])
+        elif name == "cx": sv.apply_mcx(s, [q[0]], q[1])
+        elif name == "ccx": sv.apply_mcx(s, q[:2], q[2])
+        elif name == "rz": sv.apply_1q(s, q[0], sv.rz(p[0]))
+        elif name == "ry": sv.apply_1q(s, q[0], sv.ry(p[0]))
+        elif name == "cp": sv.apply_mcphase(s, q, p[0])
+        elif name == "cz": sv.apply_mcphase(s, q, np.pi)
+        elif name == "swap":
+            sv.apply_mcx(s, [q[0]], q[1]); sv.apply_mcx(s, [q[1]], q[0]); sv.apply_mcx(s, [q[0]], q[1])
+        else: raise AssertionError(name)
+    return s
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+def test_random_circuits_all_fusion_levels(seed, fusion):
+    qc = rand_circuit(7, 60, seed)
+    amp, ing, pl, _ = run_numpy(qc, fusion=fusion)
+    assert np.abs(amp - oracle_state_of(qc)).max() < 1e-12
+    if fusion:
+        assert len(pl.ops) <= len(ing.ops) + 1
+
+
+@pytest.mark.parametrize("layout", ["auto", "reference"])
+@pytest.mark.parametrize("shards", [2, 4, 8])
+@pytest.mark.parametrize("fusion", [0, 2])
+def test_sharded_plan_matches_closed_form(shards, layout, fusion):
+    C = workloads.grid(2, 3)
+    th = random_theta(cf.model_shape(C)[3], seed=shards)
+    amp, ing, pl, eng = run_numpy(QCMRF(C, th), fusion=fusion, shards=shards, layout=layout)
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-13
+    assert eng.n_exchanges == pl.n_exchanges
+    if layout == "auto" and fusion == 2:
+        assert pl.n_exchanges == 0
+        g = shards.bit_length() - 1
+        n = cf.model_shape(C)[0]
+        shard_logical = [q for q, p in enumerate(pl.layout) if p >= ing.num_qubits - g]
+        assert all(q < n for q in shard_logical)             # variable qubits became the shard bits
+    if layout == "reference":
+        assert pl.layout != [] and pl.initial_layout == list(range(ing.num_qubits))
+        assert pl.n_exchanges > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sharded_random_circuits(seed):
+    qc = rand_circuit(8, 50, 100 + seed)
+    want = oracle_state_of(qc)
+    for shards in (2, 4):
+        for layout in ("auto", "reference"):
+            amp, _, pl, _ = run_numpy(qc, fusion=2, shards=shards, layout=layout)
+            assert np.abs(amp - want).max() < 1e-12
+
+
+def test_program_encoding_roundtrip():
+    from qcmrf_amd import _lib
+    C = workloads.chain(4)
+    qc = QCMRF(C, random_theta(12))
+    be = QsvBackend()
+    for fusion in (0, 1, 2):
+        ing, pl = be.compile(qc, fusion=fusion)
+        rec, data = program.encode(pl.ops)
+        assert rec.dtype == _lib.OP_DTYPE and len(rec) == len(pl.ops)
+        for r, op in zip(rec, pl.ops):
+            if op.kind == "mux":
+                assert r["kind"] == _lib.OP_MUX and r["target"] == op.target
+                off, cnt = int(r["data_off"]), 8 * 2 ** int(r["n"])
+                got = data[off: off + cnt].view(np.complex128).reshape(-1, 2, 2)
+                assert np.array_equal(got, op.mats)
+            if op.kind == "mcphase":
+                assert r["angle"] == op.angle and list(r["vals"][: r["n"]]) == list(op.vals)
+
+
+def test_ingest_rejects_what_it_cannot_do():
+    from qcmrf_amd.circuit import QuantumCircuit, Instruction
+    qc = QuantumCircuit(2, 2)
+    qc.h(0); qc.measure(0, 0); qc.x(0)
+    with pytest.raises(ValueError, match="after it was measured"):
+        ingest(qc)
+    qc = QuantumCircuit(2, 2)
+    qc.append(Instruction("frobnicate", 2), [0, 1])
+    with pytest.raises(ValueError, match="frobnicate"):
+        ingest(qc)
+    qc = QuantumCircuit(1, 1)
+    qc.h(0)
+    qc.data[-1].operation.condition = ("c", 1)
+    with pytest.raises(ValueError, match="conditioned"):
+        ingest(qc)
+
+
+def test_open_controls_and_ctrl_state():
+    from qcmrf_amd.circuit import QuantumCircuit, Instruction
+    qc = QuantumCircuit(3, 0)
+    qc.h(0); qc.h(1)
+    op = Instruction("ccx_o1", 3)
+    op.ctrl_state = 1                      # control 0 fires on 1, control 1 fires on 0
+    qc.append(op, [0, 1, 2])
+    amp, _, _, _ = run_numpy(qc, fusion=0)
+    s = sv.zero_state(3)
+    sv.apply_1q(s, 0, sv.MATS["h"]); sv.apply_1q(s, 1, sv.MATS["h"])
+    sv.apply_mcx(s, [0, 1], 2, [1, 0])
+    assert np.abs(amp - s).max() < 1e-15
