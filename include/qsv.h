@@ -62,6 +62,7 @@ typedef struct {
   qsv_kind_stats per_kind[QSV_K_COUNT];
   uint64_t exchanges;         /* shard-bit exchanges performed                              */
   double   exchange_bytes;    /* bytes sent over the fabric by this process                 */
+  uint64_t fused_gates;       /* gates executed inside multi-gate (QSV_K_MULTI) passes      */
 } qsv_stats;
 
 /* ---- life cycle -------------------------------------------------------------------- */

@@ -29,7 +29,8 @@ class KindStats(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("per_kind", KindStats * K_COUNT), ("exchanges", C.c_uint64), ("exchange_bytes", C.c_double)]
+    _fields_ = [("per_kind", KindStats * K_COUNT), ("exchanges", C.c_uint64), ("exchange_bytes", C.c_double),
+                ("fused_gates", C.c_uint64)]
 
 
 class QsvOp(C.Structure):
@@ -193,6 +194,11 @@ class Engine:
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         _chk(self._lib.qsv_comm_init(self._h, buf))
 
+    def comm_bootstrap(self, comm):
+        """collective over ``comm``: rank 0 mints the RCCL unique id, everyone joins"""
+        uid = comm.bcast(comm_unique_id() if comm.rank == 0 else None, src=0)
+        self.comm_init(uid)
+
     def sync(self):
         _chk(self._lib.qsv_sync(self._h))
 
@@ -301,7 +307,8 @@ class Engine:
     def stats(self):
         st = Stats()
         _chk(self._lib.qsv_get_stats(self._h, C.byref(st)))
-        out = {"exchanges": int(st.exchanges), "exchange_bytes": float(st.exchange_bytes), "kinds": {}}
+        out = {"exchanges": int(st.exchanges), "exchange_bytes": float(st.exchange_bytes),
+               "fused_gates": int(st.fused_gates), "kinds": {}}
         for i, name in enumerate(K_NAMES):
             k = st.per_kind[i]
             if k.launches:

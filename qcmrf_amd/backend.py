@@ -96,11 +96,12 @@ class QsvBackend:
     def __init__(self, name="qasm_simulator", **options):
         self._name = name
         self.options = {"fusion": 2, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
-                        "profile": False, "keep_state": False}
+                        "profile": False, "engine_options": None}
         self.options.update(options)
         self._engine = None
         self._engine_key = None
         self.last_engine = None
+        self._engine_factory = None      # test hook only; the default and only shipped engine is libqsv
 
     def name(self):
         return self._name
@@ -120,11 +121,12 @@ class QsvBackend:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        make = self._engine_factory or _lib.Engine
         if comm.world > 1:
-            eng = _lib.Engine(n_qubits, devices=(opts["device"],), rank=comm.rank, world_size=comm.world)
+            eng = make(n_qubits, devices=(opts["device"],), rank=comm.rank, world_size=comm.world)
             eng._comm_ready = False
         else:
-            eng = _lib.Engine(n_qubits, devices=tuple(opts["devices"]))
+            eng = make(n_qubits, devices=tuple(opts["devices"]))
             eng._comm_ready = True
         self._engine, self._engine_key = eng, key
         return eng
@@ -169,9 +171,10 @@ class QsvBackend:
         t1 = time.perf_counter()
 
         eng = self._get_engine(ing.num_qubits, opts)
+        for k, v in (opts["engine_options"] or {}).items():
+            eng.set_option(k, v)
         if pl.n_exchanges and not eng._comm_ready:
-            uid = comm.bcast(_lib.comm_unique_id() if comm.rank == 0 else None, src=0)
-            eng.comm_init(uid)
+            eng.comm_bootstrap(comm)         # collective: RCCL communicator over all ranks
             eng._comm_ready = True
         if opts["profile"]:
             eng.set_profiling(True)

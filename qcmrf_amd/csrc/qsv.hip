@@ -124,10 +124,11 @@ struct qsv_handle {
   bool profiling = false;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   // options
-  int opt_blocks_per_cu = 8;
+  int opt_blocks_per_cu = 1 << 16;  // measured on MI355X: one tile per workgroup (no grid-stride) streams fastest
   int opt_unroll = 4;
   int opt_lowt_shuffle = 1;
   int opt_nt = 0;
+  int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
 };
 
@@ -142,7 +143,7 @@ static unsigned grid_for(const qsv_handle* h, const Shard& s, uint64_t work, uin
   uint64_t need = (work + per_block - 1) / per_block;
   uint64_t cap = (uint64_t)s.n_cu * (uint64_t)h->opt_blocks_per_cu;
   if (need < 1) need = 1;
-  return (unsigned)std::min(need, cap);
+  return (unsigned)std::min<uint64_t>(std::min(need, cap), 0x7fffffffull);
 }
 
 // device copy of a small host table, asynchronous on the shard stream
@@ -423,115 +424,24 @@ extern "C" int qsv_init_uniform(qsv_handle* h, uint64_t qubit_mask) {
 extern "C" int qsv_init_zero(qsv_handle* h) { return qsv_init_uniform(h, 0ull); }
 
 // ------------------------------------------------------------------------------------------
-// (multi-controlled) 2x2 and X
+// gates: every gate is first RESOLVED per shard (shard-bit controls evaluated, tables sliced)
+// into a LocalOp on local address bits, then either launched alone (dedicated kernel) or
+// grouped with its neighbours into one register-tiled k_multi pass (qsv_exec).
 // ------------------------------------------------------------------------------------------
-template <int KIND, bool NT>
-static void launch_pair(const qsv_handle* h, const Shard& s, uint64_t npairs, const BitIns& ins,
-                        uint64_t fixed, uint64_t tbit, const Mat2& m) {
-  const int U = h->opt_unroll;
-  if (U >= 4 && npairs % (QSV_TPB * 4) == 0)
-    hipLaunchKernelGGL((k_pair<KIND, 4, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 4)), dim3(QSV_TPB), 0,
-                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
-  else if (U >= 2 && npairs % (QSV_TPB * 2) == 0)
-    hipLaunchKernelGGL((k_pair<KIND, 2, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 2)), dim3(QSV_TPB), 0,
-                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
-  else
-    hipLaunchKernelGGL((k_pair<KIND, 1, true, NT>), dim3(grid_for(h, s, npairs, QSV_TPB)), dim3(QSV_TPB), 0,
-                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
-}
-
-static int apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* vals, int t,
-                      const double* m, bool is_x) {
-  if (!h) return fail(QSV_E_BADARG, "NULL handle");
-  if (n_ctrl < 0 || n_ctrl > QSV_MAX_CTRL) return fail(QSV_E_BADARG, "n_ctrl %d out of range", n_ctrl);
-  if (n_ctrl && !ctrls) return fail(QSV_E_BADARG, "ctrls is NULL");
-  CHK(check_qubit(h, t, "target"));
-  CHK(check_distinct(h, n_ctrl, ctrls, t));
-  if (t >= h->L)
-    return fail(QSV_E_UNSUPPORTED, "target qubit %d is a shard bit (local qubits: %d); qsv_swap_layout it first", t, h->L);
-  Mat2 mm;
-  if (is_x) memset(&mm, 0, sizeof mm);
-  else {
-    if (!m) return fail(QSV_E_BADARG, "matrix is NULL");
-    memcpy(mm.v, m, sizeof mm.v);
-  }
-  const uint64_t n = amps_local(h);
-  for (Shard& s : h->shards) {
-    LocalCtrl lc = resolve_ctrl(h, s, n_ctrl, ctrls, vals);
-    if (lc.skip) continue;
-    CHK(shard_set(s));
-    const int nc = (int)lc.q.size();
-    const uint64_t npairs = n >> (1 + nc);
-    const double bytes = 32.0 * (double)(n >> nc);
-    const int kind = is_x ? QSV_K_X : QSV_K_1Q;
-    // low target, no controls, dense: wave-shuffle kernel
-    if (!is_x && nc == 0 && t < 6 && h->opt_lowt_shuffle && n % (QSV_TPB * 4) == 0) {
-      CHK(launch(h, s, kind, bytes, [&] {
-        if (h->opt_nt)
-          hipLaunchKernelGGL((k_lowt<4, true>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
-                             s.amp, n, t, mm);
-        else
-          hipLaunchKernelGGL((k_lowt<4, false>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
-                             s.amp, n, t, mm);
-      }));
-      continue;
-    }
-    std::vector<int> pos = lc.q;
-    pos.push_back(t);
-    const BitIns ins = make_ins(pos);
-    uint64_t fixed = 0;
-    for (int i = 0; i < nc; ++i) if (lc.v[i]) fixed |= 1ull << lc.q[i];
-    const uint64_t tbit = 1ull << t;
-    CHK(launch(h, s, kind, bytes, [&] {
-      if (is_x) { if (h->opt_nt) launch_pair<1, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<1, false>(h, s, npairs, ins, fixed, tbit, mm); }
-      else      { if (h->opt_nt) launch_pair<0, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<0, false>(h, s, npairs, ins, fixed, tbit, mm); }
-    }));
-  }
-  return QSV_OK;
-}
-
-extern "C" int qsv_apply_1q(qsv_handle* h, int t, const double m[8]) { return apply_mc1q(h, 0, nullptr, nullptr, t, m, false); }
-extern "C" int qsv_apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t, const double m[8]) {
-  return apply_mc1q(h, n_ctrl, ctrls, ctrl_vals, t, m, false);
-}
-extern "C" int qsv_apply_mcx(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t) {
-  return apply_mc1q(h, n_ctrl, ctrls, ctrl_vals, t, nullptr, true);
-}
-
-// ------------------------------------------------------------------------------------------
-// diagonal family
-// ------------------------------------------------------------------------------------------
-extern "C" int qsv_apply_mcphase(qsv_handle* h, int n_ctrl, const int* ctrls, const int* vals, double angle) {
-  if (!h) return fail(QSV_E_BADARG, "NULL handle");
-  if (n_ctrl < 1 || n_ctrl > QSV_MAX_CTRL || !ctrls) return fail(QSV_E_BADARG, "mcphase needs 1..%d qubits", QSV_MAX_CTRL);
-  CHK(check_distinct(h, n_ctrl, ctrls, -1));
-  const cplx ph = make_double2(std::cos(angle), std::sin(angle));
-  const uint64_t n = amps_local(h);
-  for (Shard& s : h->shards) {
-    LocalCtrl lc = resolve_ctrl(h, s, n_ctrl, ctrls, vals);
-    if (lc.skip) continue;
-    CHK(shard_set(s));
-    const int nc = (int)lc.q.size();
-    const uint64_t nsub = n >> nc;
-    const BitIns ins = make_ins(lc.q);
-    uint64_t fixed = 0;
-    for (int i = 0; i < nc; ++i) if (lc.v[i]) fixed |= 1ull << lc.q[i];
-    CHK(launch(h, s, QSV_K_MCPHASE, 32.0 * (double)nsub, [&] {
-      if (nsub % (QSV_TPB * 4) == 0)
-        hipLaunchKernelGGL((k_mcphase<4, false>), dim3(grid_for(h, s, nsub, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
-                           s.amp, nsub, ins, fixed, ph);
-      else
-        hipLaunchKernelGGL((k_mcphase<1, true>), dim3(grid_for(h, s, nsub, QSV_TPB)), dim3(QSV_TPB), 0, s.stream,
-                           s.amp, nsub, ins, fixed, ph);
-    }));
-  }
-  return QSV_OK;
-}
+struct LocalOp {
+  int type = 0;               // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase
+  bool is_x = false;          // type 2 that is a plain X: swap kernel when launched alone
+  int target = -1;            // local address bit (types 0, 2)
+  std::vector<int> list;      // types 0,1: gather list; table index bit e <- address bit list[e]
+  std::vector<double> table;  // type 0: 8 doubles per entry; type 1: 2 doubles per entry
+  std::vector<int> cq, cv;    // types 2,3: local controls and their values
+  double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
 
 // slice a 2^k table (entry = `ent` doubles) over `qubits` down to the local qubits of shard s
 static void slice_table(const qsv_handle* h, const Shard& s, int k, const int* qubits, const double* table,
                         int ent, std::vector<int>& lq, std::vector<double>& out) {
-  std::vector<int> lpos;   // positions (within the k-list) that are local
+  std::vector<int> lpos;
   uint32_t gfix = 0;
   lq.clear();
   for (int b = 0; b < k; ++b) {
@@ -547,26 +457,139 @@ static void slice_table(const qsv_handle* h, const Shard& s, int k, const int* q
   }
 }
 
-extern "C" int qsv_apply_diag(qsv_handle* h, int k, const int* qubits, const double* table) {
-  if (!h) return fail(QSV_E_BADARG, "NULL handle");
-  if (k < 1 || k > QSV_MAX_CTRL || !qubits || !table) return fail(QSV_E_BADARG, "diag needs 1..%d qubits and a table", QSV_MAX_CTRL);
-  CHK(check_distinct(h, k, qubits, -1));
+// argument validation shared by the one-gate entry points and qsv_exec
+static int validate_gate(const qsv_handle* h, int kind, int n, const int* q, int target, const void* data) {
+  switch (kind) {
+    case QSV_OP_1Q: case QSV_OP_MCX:
+      if (n < 0 || n > QSV_MAX_CTRL || (n && !q)) return fail(QSV_E_BADARG, "n_ctrl %d out of range", n);
+      CHK(check_qubit(h, target, "target"));
+      CHK(check_distinct(h, n, q, target));
+      if (kind == QSV_OP_1Q && !data) return fail(QSV_E_BADARG, "matrix is NULL");
+      break;
+    case QSV_OP_MUX:
+      if (n < 0 || n > 10 || (n && !q) || !data) return fail(QSV_E_BADARG, "mux needs 0..10 controls and matrices");
+      CHK(check_qubit(h, target, "target"));
+      CHK(check_distinct(h, n, q, target));
+      break;
+    case QSV_OP_DIAG:
+      if (n < 1 || n > QSV_MAX_CTRL || !q || !data) return fail(QSV_E_BADARG, "diag needs 1..%d qubits and a table", QSV_MAX_CTRL);
+      CHK(check_distinct(h, n, q, -1));
+      return QSV_OK;
+    case QSV_OP_MCPHASE:
+      if (n < 1 || n > QSV_MAX_CTRL || !q) return fail(QSV_E_BADARG, "mcphase needs 1..%d qubits", QSV_MAX_CTRL);
+      CHK(check_distinct(h, n, q, -1));
+      return QSV_OK;
+    default:
+      return fail(QSV_E_BADARG, "not a gate kind: %d", kind);
+  }
+  if (target >= h->L)
+    return fail(QSV_E_UNSUPPORTED, "target qubit %d is a shard bit (local qubits: %d); qsv_swap_layout it first", target, h->L);
+  return QSV_OK;
+}
+
+// false: this shard is untouched by the gate (a shard-bit control does not match)
+static bool resolve_gate(const qsv_handle* h, const Shard& s, int kind, int n, const int* q, const int* vals,
+                         int target, const double* data, double angle, LocalOp& lo) {
+  lo = LocalOp();
+  if (kind == QSV_OP_1Q || kind == QSV_OP_MCX || kind == QSV_OP_MCPHASE) {
+    LocalCtrl lc = resolve_ctrl(h, s, n, q, vals);
+    if (lc.skip) return false;
+    lo.cq = lc.q;
+    lo.cv = lc.v;
+    if (kind == QSV_OP_MCPHASE) {
+      lo.type = 3;
+      lo.m[0] = std::cos(angle);
+      lo.m[1] = std::sin(angle);
+    } else {
+      lo.type = 2;
+      lo.target = target;
+      lo.is_x = kind == QSV_OP_MCX;
+      if (lo.is_x) { lo.m[2] = 1.0; lo.m[4] = 1.0; }
+      else memcpy(lo.m, data, sizeof lo.m);
+    }
+    return true;
+  }
+  if (kind == QSV_OP_MUX) {
+    lo.type = 0;
+    lo.target = target;
+    slice_table(h, s, n, q, data, 8, lo.list, lo.table);
+  } else {
+    lo.type = 1;
+    slice_table(h, s, n, q, data, 2, lo.list, lo.table);
+  }
+  return true;
+}
+
+template <int KIND, bool NT>
+static void launch_pair(const qsv_handle* h, const Shard& s, uint64_t npairs, const BitIns& ins,
+                        uint64_t fixed, uint64_t tbit, const Mat2& m) {
+  const int U = h->opt_unroll;
+  if (U >= 4 && npairs % (QSV_TPB * 4) == 0)
+    hipLaunchKernelGGL((k_pair<KIND, 4, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 4)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+  else if (U >= 2 && npairs % (QSV_TPB * 2) == 0)
+    hipLaunchKernelGGL((k_pair<KIND, 2, false, NT>), dim3(grid_for(h, s, npairs, QSV_TPB * 2)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+  else
+    hipLaunchKernelGGL((k_pair<KIND, 1, true, NT>), dim3(grid_for(h, s, npairs, QSV_TPB)), dim3(QSV_TPB), 0,
+                       s.stream, s.amp, npairs, ins, fixed, tbit, m);
+}
+
+// one resolved gate, one dedicated kernel
+static int run_single(qsv_handle* h, Shard& s, const LocalOp& lo) {
+  CHK(shard_set(s));
   const uint64_t n = amps_local(h);
-  std::vector<int> lq;
-  std::vector<double> sub;
-  for (Shard& s : h->shards) {
-    CHK(shard_set(s));
-    slice_table(h, s, k, qubits, table, 2, lq, sub);
-    const int kl = (int)lq.size();
+  if (lo.type == 2) {
+    const int nc = (int)lo.cq.size(), t = lo.target;
+    const uint64_t npairs = n >> (1 + nc);
+    const double bytes = 32.0 * (double)(n >> nc);
+    const int kind = lo.is_x ? QSV_K_X : QSV_K_1Q;
+    Mat2 mm;
+    memcpy(mm.v, lo.m, sizeof mm.v);
+    if (!lo.is_x && nc == 0 && t < 6 && h->opt_lowt_shuffle && n % (QSV_TPB * 4) == 0) {
+      return launch(h, s, kind, bytes, [&] {
+        if (h->opt_nt)
+          hipLaunchKernelGGL((k_lowt<4, true>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, n, t, mm);
+        else
+          hipLaunchKernelGGL((k_lowt<4, false>), dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, n, t, mm);
+      });
+    }
+    std::vector<int> pos = lo.cq;
+    pos.push_back(t);
+    const BitIns ins = make_ins(pos);
+    uint64_t fixed = 0;
+    for (int i = 0; i < nc; ++i) if (lo.cv[i]) fixed |= 1ull << lo.cq[i];
+    const uint64_t tbit = 1ull << t;
+    return launch(h, s, kind, bytes, [&] {
+      if (lo.is_x) { if (h->opt_nt) launch_pair<1, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<1, false>(h, s, npairs, ins, fixed, tbit, mm); }
+      else         { if (h->opt_nt) launch_pair<0, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<0, false>(h, s, npairs, ins, fixed, tbit, mm); }
+    });
+  }
+  if (lo.type == 3) {
+    const int nc = (int)lo.cq.size();
+    const uint64_t nsub = n >> nc;
+    const BitIns ins = make_ins(lo.cq);
+    uint64_t fixed = 0;
+    for (int i = 0; i < nc; ++i) if (lo.cv[i]) fixed |= 1ull << lo.cq[i];
+    const cplx ph = make_double2(lo.m[0], lo.m[1]);
+    return launch(h, s, QSV_K_MCPHASE, 32.0 * (double)nsub, [&] {
+      if (nsub % (QSV_TPB * 4) == 0)
+        hipLaunchKernelGGL((k_mcphase<4, false>), dim3(grid_for(h, s, nsub, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, nsub, ins, fixed, ph);
+      else
+        hipLaunchKernelGGL((k_mcphase<1, true>), dim3(grid_for(h, s, nsub, QSV_TPB)), dim3(QSV_TPB), 0, s.stream, s.amp, nsub, ins, fixed, ph);
+    });
+  }
+  const int kl = (int)lo.list.size();
+  void* dtab = nullptr;
+  CHK(arena_put(s, lo.table.data(), lo.table.size() * sizeof(double), &dtab));
+  BitList bl;
+  bl.n = kl;
+  for (int b = 0; b < kl; ++b) bl.pos[b] = lo.list[b];
+  if (lo.type == 1) {
     const int ntab = 1 << kl;
-    void* dtab = nullptr;
-    CHK(arena_put(s, sub.data(), sub.size() * sizeof(double), &dtab));
-    BitList bl;
-    bl.n = kl;
-    for (int b = 0; b < kl; ++b) bl.pos[b] = lq[b];
     const bool lds = kl <= 11;
     const size_t shm = lds ? (size_t)ntab * sizeof(cplx) : 0;
-    CHK(launch(h, s, QSV_K_DIAG, 32.0 * (double)n, [&] {
+    return launch(h, s, QSV_K_DIAG, 32.0 * (double)n, [&] {
       const cplx* tp = reinterpret_cast<const cplx*>(dtab);
       if (n % (QSV_TPB * 4) == 0) {
         const dim3 g(grid_for(h, s, n, QSV_TPB * 4));
@@ -579,49 +602,181 @@ extern "C" int qsv_apply_diag(qsv_handle* h, int k, const int* qubits, const dou
         if (lds) hipLaunchKernelGGL((k_diag<1, true, true, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, n, bl, tp, ntab);
         else     hipLaunchKernelGGL((k_diag<1, true, false, false>), g, dim3(QSV_TPB), 0, s.stream, s.amp, n, bl, tp, ntab);
       }
-    }));
+    });
   }
+  // type 0: uniformly controlled 2x2
+  const int nmat = 1 << kl, t = lo.target;
+  const uint64_t npairs = n >> 1;
+  const size_t shm = (size_t)nmat * 64;
+  return launch(h, s, QSV_K_MUX, 32.0 * (double)n, [&] {
+    const double* mp = reinterpret_cast<const double*>(dtab);
+    if (npairs % (QSV_TPB * 4) == 0 && h->opt_unroll >= 4) {
+      const dim3 g(grid_for(h, s, npairs, QSV_TPB * 4));
+      if (h->opt_nt) hipLaunchKernelGGL((k_mux<4, false, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+      else           hipLaunchKernelGGL((k_mux<4, false, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+    } else if (npairs % (QSV_TPB * 2) == 0) {
+      hipLaunchKernelGGL((k_mux<2, false, false>), dim3(grid_for(h, s, npairs, QSV_TPB * 2)), dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+    } else {
+      hipLaunchKernelGGL((k_mux<1, true, false>), dim3(grid_for(h, s, npairs, QSV_TPB)), dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
+    }
+  });
+}
+
+static int apply_gate(qsv_handle* h, int kind, int n, const int* q, const int* vals, int target,
+                      const double* data, double angle) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  CHK(validate_gate(h, kind, n, q, target, kind == QSV_OP_MCX || kind == QSV_OP_MCPHASE ? (const void*)h : (const void*)data));
+  LocalOp lo;
+  for (Shard& s : h->shards)
+    if (resolve_gate(h, s, kind, n, q, vals, target, data, angle, lo)) CHK(run_single(h, s, lo));
   return QSV_OK;
 }
 
+extern "C" int qsv_apply_1q(qsv_handle* h, int t, const double m[8]) { return apply_gate(h, QSV_OP_1Q, 0, nullptr, nullptr, t, m, 0); }
+extern "C" int qsv_apply_mc1q(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t, const double m[8]) {
+  return apply_gate(h, QSV_OP_1Q, n_ctrl, ctrls, ctrl_vals, t, m, 0);
+}
+extern "C" int qsv_apply_mcx(qsv_handle* h, int n_ctrl, const int* ctrls, const int* ctrl_vals, int t) {
+  return apply_gate(h, QSV_OP_MCX, n_ctrl, ctrls, ctrl_vals, t, nullptr, 0);
+}
+extern "C" int qsv_apply_mcphase(qsv_handle* h, int n_ctrl, const int* ctrls, const int* vals, double angle) {
+  return apply_gate(h, QSV_OP_MCPHASE, n_ctrl, ctrls, vals, -1, nullptr, angle);
+}
+extern "C" int qsv_apply_diag(qsv_handle* h, int k, const int* qubits, const double* table) {
+  return apply_gate(h, QSV_OP_DIAG, k, qubits, nullptr, -1, table, 0);
+}
 extern "C" int qsv_apply_mux_1q(qsv_handle* h, int k, const int* ctrls, int t, const double* mats) {
-  if (!h) return fail(QSV_E_BADARG, "NULL handle");
-  if (k < 0 || k > 10 || (k && !ctrls) || !mats) return fail(QSV_E_BADARG, "mux needs 0..10 controls and matrices");
-  CHK(check_qubit(h, t, "target"));
-  CHK(check_distinct(h, k, ctrls, t));
-  if (t >= h->L)
-    return fail(QSV_E_UNSUPPORTED, "target qubit %d is a shard bit (local qubits: %d); qsv_swap_layout it first", t, h->L);
+  return apply_gate(h, QSV_OP_MUX, k, ctrls, nullptr, t, mats, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_multi pass: a run of resolved gates on <= opt_multi_r distinct targets, one HBM sweep
+// ------------------------------------------------------------------------------------------
+struct PendingGroup {
+  std::vector<LocalOp> ops;
+  std::vector<int> targets;       // distinct target bits, in first-use order
+  size_t table_cplx = 0;
+  bool init = false;              // an init write is waiting to be merged into the pass
+  uint64_t nonmask = 0;
+  double initval = 0;
+};
+
+static bool groupable(const qsv_handle* h, const LocalOp& lo) {
+  if (h->opt_multi_r < 1) return false;
+  if ((lo.type == 0 || lo.type == 1) && (int)lo.list.size() > QSV_MULTI_MAXLIST) return false;
+  return true;
+}
+static size_t table_cplx_of(const LocalOp& lo) {
+  if (lo.type == 0) return (size_t)4 << lo.list.size();
+  if (lo.type == 1) return (size_t)1 << lo.list.size();
+  return 0;
+}
+static bool group_fits(const qsv_handle* h, const PendingGroup& g, const LocalOp& lo) {
+  size_t nt = g.targets.size();
+  if (lo.target >= 0 && std::find(g.targets.begin(), g.targets.end(), lo.target) == g.targets.end()) ++nt;
+  if ((int)nt > h->opt_multi_r) return false;
+  if (g.table_cplx + table_cplx_of(lo) > 2560) return false;      // 40 KiB of LDS tables
+  return g.ops.size() < 64;
+}
+
+template <int R>
+static void launch_multi(const qsv_handle* h, const Shard& s, bool init, uint64_t nthreads, const BitIns& ins,
+                         const RegPos& rp, const MultiOp* dops, int nops, const cplx* dtab, int ntab,
+                         uint64_t nonmask, double initval) {
+  const dim3 g((unsigned)((nthreads + QSV_TPB - 1) / QSV_TPB));
+  const size_t shm = (size_t)std::max(ntab, 1) * sizeof(cplx);
+  if (init) hipLaunchKernelGGL((k_multi<R, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, nops, dtab, ntab, nonmask, initval);
+  else      hipLaunchKernelGGL((k_multi<R, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, nops, dtab, ntab, nonmask, initval);
+}
+
+static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   const uint64_t n = amps_local(h);
-  const uint64_t npairs = n >> 1;
-  std::vector<int> lq;
-  std::vector<double> sub;
-  for (Shard& s : h->shards) {
-    CHK(shard_set(s));
-    slice_table(h, s, k, ctrls, mats, 8, lq, sub);
-    const int kl = (int)lq.size();
-    const int nmat = 1 << kl;
-    void* dtab = nullptr;
-    CHK(arena_put(s, sub.data(), sub.size() * sizeof(double), &dtab));
-    BitList bl;
-    bl.n = kl;
-    for (int b = 0; b < kl; ++b) bl.pos[b] = lq[b];
-    const size_t shm = (size_t)nmat * 64;
-    CHK(launch(h, s, QSV_K_MUX, 32.0 * (double)n, [&] {
-      const double* mp = reinterpret_cast<const double*>(dtab);
-      if (npairs % (QSV_TPB * 4) == 0 && h->opt_unroll >= 4) {
-        const dim3 g(grid_for(h, s, npairs, QSV_TPB * 4));
-        if (h->opt_nt) hipLaunchKernelGGL((k_mux<4, false, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
-        else           hipLaunchKernelGGL((k_mux<4, false, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
-      } else if (npairs % (QSV_TPB * 2) == 0) {
-        const dim3 g(grid_for(h, s, npairs, QSV_TPB * 2));
-        hipLaunchKernelGGL((k_mux<2, false, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
-      } else {
-        const dim3 g(grid_for(h, s, npairs, QSV_TPB));
-        hipLaunchKernelGGL((k_mux<1, true, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, npairs, t, bl, mp, nmat);
-      }
-    }));
+  CHK(shard_set(s));
+  if (g.ops.empty()) {
+    if (g.init) {
+      CHK(launch(h, s, QSV_K_INIT, 16.0 * (double)n, [&] {
+        hipLaunchKernelGGL(k_init, dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, n, g.nonmask, g.initval);
+      }));
+    }
+    g = PendingGroup();
+    return QSV_OK;
   }
-  return QSV_OK;
+  if (g.ops.size() == 1 && !g.init) {
+    const int r = run_single(h, s, g.ops[0]);
+    g = PendingGroup();
+    return r;
+  }
+  // register bits: the targets, padded with free bits >= 6 so every lane keeps >= 8 loads in flight
+  std::vector<int> reg = g.targets;
+  const int want = std::min(h->L, std::max((int)reg.size(), std::min(3, h->opt_multi_r)));
+  for (int b = std::min(6, h->L - 1); (int)reg.size() < want && b < h->L; ++b)
+    if (std::find(reg.begin(), reg.end(), b) == reg.end()) reg.push_back(b);
+  for (int b = 0; (int)reg.size() < want && b < h->L; ++b)
+    if (std::find(reg.begin(), reg.end(), b) == reg.end()) reg.push_back(b);
+  const int R = (int)reg.size();
+  RegPos rp;
+  memset(&rp, 0, sizeof rp);
+  for (int c = 0; c < R; ++c) rp.pos[c] = reg[c];
+  const BitIns ins = make_ins(reg);
+  auto reg_index = [&](int q) -> int {
+    for (int c = 0; c < R; ++c) if (reg[c] == q) return c;
+    return -1;
+  };
+  std::vector<MultiOp> mops(g.ops.size());
+  std::vector<double> tables;
+  for (size_t i = 0; i < g.ops.size(); ++i) {
+    const LocalOp& lo = g.ops[i];
+    MultiOp& mo = mops[i];
+    memset(&mo, 0, sizeof mo);
+    mo.type = lo.type;
+    mo.bit = lo.target >= 0 ? reg_index(lo.target) : 0;
+    mo.uniform = 1;
+    if (lo.type == 0 || lo.type == 1) {
+      mo.nlist = (int)lo.list.size();
+      mo.tab = (int)(tables.size() / 2);
+      for (int e = 0; e < mo.nlist; ++e) {
+        const int c = reg_index(lo.list[e]);
+        if (c >= 0) { mo.pos[e] = -1; mo.regw[c] = (lo.type == 0 ? 1 : 1) << e; mo.uniform = 0; }
+        else mo.pos[e] = lo.list[e];
+      }
+      tables.insert(tables.end(), lo.table.begin(), lo.table.end());
+    } else {
+      for (size_t k = 0; k < lo.cq.size(); ++k) {
+        const int c = reg_index(lo.cq[k]);
+        if (c >= 0) { mo.rmask |= 1u << c; if (lo.cv[k]) mo.rval |= 1u << c; }
+        else { mo.tmask |= 1ull << lo.cq[k]; if (lo.cv[k]) mo.tval |= 1ull << lo.cq[k]; }
+      }
+      memcpy(mo.m, lo.m, sizeof mo.m);
+    }
+  }
+  void* dops = nullptr;
+  void* dtab = nullptr;
+  CHK(arena_put(s, mops.data(), mops.size() * sizeof(MultiOp), &dops));
+  if (tables.empty()) tables.assign(2, 0.0);
+  CHK(arena_put(s, tables.data(), tables.size() * sizeof(double), &dtab));
+  const int ntab = (int)(tables.size() / 2);
+  const uint64_t nthreads = n >> R;
+  const double bytes = (g.init ? 16.0 : 32.0) * (double)n;
+  h->stats.fused_gates += g.ops.size();
+  const bool init = g.init;
+  const uint64_t nonmask = g.nonmask;
+  const double initval = g.initval;
+  const int nops = (int)mops.size();
+  const int r = launch(h, s, QSV_K_MULTI, bytes, [&] {
+    const MultiOp* o = reinterpret_cast<const MultiOp*>(dops);
+    const cplx* tp = reinterpret_cast<const cplx*>(dtab);
+    switch (R) {
+      case 0: launch_multi<0>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 1: launch_multi<1>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 2: launch_multi<2>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 3: launch_multi<3>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 4: launch_multi<4>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 5: launch_multi<5>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      default: launch_multi<6>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+    }
+  });
+  g = PendingGroup();
+  return r;
 }
 
 template <int K>
@@ -968,10 +1123,16 @@ extern "C" int qsv_get_amplitudes(qsv_handle* h, uint64_t start, uint64_t count,
 extern "C" int qsv_set_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, const double* in) { return amp_copy(h, start, count, nullptr, in); }
 
 // ------------------------------------------------------------------------------------------
-// batched execution
+// batched execution: resolve per shard, block consecutive gates into k_multi passes
 // ------------------------------------------------------------------------------------------
 extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const double* data, uint64_t n_data) {
   if (!h || (n_ops && !ops)) return fail(QSV_E_BADARG, "NULL argument");
+  const size_t ns = h->shards.size();
+  std::vector<PendingGroup> pend(ns);
+  auto flush_all = [&]() -> int {
+    for (size_t i = 0; i < ns; ++i) CHK(flush_group(h, h->shards[i], pend[i]));
+    return QSV_OK;
+  };
   for (int i = 0; i < n_ops; ++i) {
     const qsv_op& o = ops[i];
     if (o.n < 0 || o.n > QSV_MAX_CTRL) return fail(QSV_E_BADARG, "op %d: n=%d out of range", i, o.n);
@@ -981,22 +1142,59 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
                                                           (unsigned long long)o.data_off, (unsigned long long)cnt, (unsigned long long)n_data);
       return QSV_OK;
     };
-    int r = QSV_OK;
     switch (o.kind) {
-      case QSV_OP_INIT_ZERO: r = qsv_init_zero(h); break;
-      case QSV_OP_INIT_UNIFORM: r = qsv_init_uniform(h, o.mask); break;
-      case QSV_OP_1Q: r = need(8); if (!r) r = apply_mc1q(h, o.n, o.qubits, o.vals, o.target, d, false); break;
-      case QSV_OP_MCX: r = apply_mc1q(h, o.n, o.qubits, o.vals, o.target, nullptr, true); break;
-      case QSV_OP_DIAG: r = need(2ull << o.n); if (!r) r = qsv_apply_diag(h, o.n, o.qubits, d); break;
-      case QSV_OP_MCPHASE: r = qsv_apply_mcphase(h, o.n, o.qubits, o.vals, o.angle); break;
-      case QSV_OP_MUX: r = need(8ull << o.n); if (!r) r = qsv_apply_mux_1q(h, o.n, o.qubits, o.target, d); break;
-      case QSV_OP_KQ: r = need(2ull << (2 * o.n)); if (!r) r = qsv_apply_kq(h, o.n, o.qubits, d); break;
-      case QSV_OP_SWAP: r = qsv_swap_layout(h, o.n, o.qubits, o.vals); break;
-      default: r = fail(QSV_E_BADARG, "op %d: unknown kind %d", i, o.kind);
+      case QSV_OP_INIT_ZERO:
+      case QSV_OP_INIT_UNIFORM: {
+        CHK(flush_all());
+        const uint64_t mask = o.kind == QSV_OP_INIT_ZERO ? 0ull : o.mask;
+        if (h->W < 64 && (mask >> h->W)) return fail(QSV_E_BADARG, "mask has bits beyond qubit %d", h->W - 1);
+        if (h->opt_multi_r < 1) { CHK(qsv_init_uniform(h, mask)); break; }
+        const double val = std::pow(2.0, -0.5 * __builtin_popcountll(mask));
+        for (size_t k = 0; k < ns; ++k) {
+          const Shard& s = h->shards[k];
+          const uint64_t hi = (uint64_t)s.index << h->L;
+          pend[k].init = true;
+          pend[k].initval = (hi & ~mask) ? 0.0 : val;
+          pend[k].nonmask = ~mask & (amps_local(h) - 1);
+        }
+        break;
+      }
+      case QSV_OP_1Q: case QSV_OP_MCX: case QSV_OP_DIAG: case QSV_OP_MCPHASE: case QSV_OP_MUX: {
+        if (o.kind == QSV_OP_1Q) CHK(need(8));
+        if (o.kind == QSV_OP_DIAG) CHK(need(2ull << o.n));
+        if (o.kind == QSV_OP_MUX) CHK(need(8ull << o.n));
+        CHK(validate_gate(h, o.kind, o.n, o.qubits, o.target, o.kind == QSV_OP_MCX || o.kind == QSV_OP_MCPHASE ? (const void*)h : (const void*)d));
+        LocalOp lo;
+        for (size_t k = 0; k < ns; ++k) {
+          Shard& s = h->shards[k];
+          if (!resolve_gate(h, s, o.kind, o.n, o.qubits, o.vals, o.target, d, o.angle, lo)) continue;
+          if (!groupable(h, lo)) {
+            CHK(flush_group(h, s, pend[k]));
+            CHK(run_single(h, s, lo));
+            continue;
+          }
+          if (!group_fits(h, pend[k], lo)) CHK(flush_group(h, s, pend[k]));
+          if (lo.target >= 0 && std::find(pend[k].targets.begin(), pend[k].targets.end(), lo.target) == pend[k].targets.end())
+            pend[k].targets.push_back(lo.target);
+          pend[k].table_cplx += table_cplx_of(lo);
+          pend[k].ops.push_back(std::move(lo));
+        }
+        break;
+      }
+      case QSV_OP_KQ:
+        CHK(flush_all());
+        CHK(need(2ull << (2 * o.n)));
+        CHK(qsv_apply_kq(h, o.n, o.qubits, d));
+        break;
+      case QSV_OP_SWAP:
+        CHK(flush_all());
+        CHK(qsv_swap_layout(h, o.n, o.qubits, o.vals));
+        break;
+      default:
+        return fail(QSV_E_BADARG, "op %d: unknown kind %d", i, o.kind);
     }
-    if (r != QSV_OK) return r;
   }
-  return QSV_OK;
+  return flush_all();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1046,6 +1244,7 @@ extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "unroll")) h->opt_unroll = value;
   else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
   else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "multi_r")) { if (value < 0 || value > QSV_MULTI_MAXR) return fail(QSV_E_BADARG, "multi_r out of range"); h->opt_multi_r = value; }
   else if (!strcmp(name, "exchange_chunk_log2")) { if (value < 4 || value > 32) return fail(QSV_E_BADARG, "exchange_chunk_log2 out of range"); h->opt_xchunk = 1ull << value; }
   else return fail(QSV_E_BADARG, "unknown option %s", name);
   return QSV_OK;

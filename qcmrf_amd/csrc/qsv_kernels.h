@@ -420,3 +420,160 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
       if (lds_acc[i] != 0.0) atomicAdd(&out[i], lds_acc[i]);
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// k_multi<R>: register-tiled multi-gate sweep -- several gates per HBM pass.
+//
+// Each lane owns the 2^R amplitudes that differ only in R "register bits" (the target qubits of
+// the gates of this pass).  With every register bit >= 6 the lane id supplies address bits 0..5,
+// so each of the 2^R loads of a wavefront is one contiguous 1 KiB global_load_dwordx4; the whole
+// 2^R-dimensional subspace a gate needs is then in the lane's own VGPRs (R = 6: 64 complex128 =
+// 256 of the 512 VGPRs a CDNA4 lane may hold) -- no LDS traffic, no shuffles, no barriers for
+// the amplitudes.  LDS holds only the gate tables.  Gates are applied in program order; controls
+// and diagonal selects may sit on any bit (register, lane or block bits).
+// HBM traffic: one read + one write of the shard (32 B / amplitude) for up to ~a dozen gates.
+// ---------------------------------------------------------------------------------------
+#define QSV_MULTI_MAXR 6
+#define QSV_MULTI_MAXLIST 10
+
+struct MultiOp {
+  int type;                       // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase
+  int bit;                        // register bit of the target (types 0, 2)
+  int uniform;                    // 1: table index / condition independent of the register bits
+  int nlist;                      // entries of pos[] (types 0, 1)
+  int tab;                        // table offset in LDS, in complex128 units
+  int regw[QSV_MULTI_MAXR];       // types 0,1: table-index weight of register bit c
+  int pos[QSV_MULTI_MAXLIST];     // types 0,1: address bit of list entry e; -1 if it is a register bit
+  unsigned int rmask, rval;       // types 2,3: condition on the register index
+  unsigned long long tmask, tval; // types 2,3: condition on the lane/block part of the address
+  double m[8];                    // type 2: 2x2 row-major {re,im}; type 3: m[0..1] = phase
+};
+struct RegPos { int pos[QSV_MULTI_MAXR]; };
+
+template <int R, int B>
+__device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
+                                              const cplx* __restrict__ lt) {
+  constexpr int NP = (R > 0) ? (1 << (R - 1)) : 0;
+  if (op.type == 0) {
+    uint32_t jt = 0;
+    for (int e = 0; e < op.nlist; ++e)
+      if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
+    if (op.uniform) {
+      const cplx* mp = lt + op.tab + 4 * jt;
+      const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+        const cplx x = a[j0], y = a[j1];
+        a[j0] = cmad(m01, y, cmul(m00, x));
+        a[j1] = cmad(m11, y, cmul(m10, x));
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+        int jr = 0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) if ((j0 >> c) & 1) jr += op.regw[c];
+        const cplx* mp = lt + op.tab + 4 * (jt + jr);
+        const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+        const cplx x = a[j0], y = a[j1];
+        a[j0] = cmad(m01, y, cmul(m00, x));
+        a[j1] = cmad(m11, y, cmul(m10, x));
+      }
+    }
+  } else {   // type 2: one matrix where the controls match
+    const bool ct = (base & op.tmask) == op.tval;
+    const cplx m00 = make_double2(op.m[0], op.m[1]), m01 = make_double2(op.m[2], op.m[3]);
+    const cplx m10 = make_double2(op.m[4], op.m[5]), m11 = make_double2(op.m[6], op.m[7]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+      if ((((unsigned)j0 & op.rmask) == op.rval) && ct) {
+        const cplx x = a[j0], y = a[j1];
+        a[j0] = cmad(m01, y, cmul(m00, x));
+        a[j1] = cmad(m11, y, cmul(m10, x));
+      }
+    }
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
+                                           const cplx* __restrict__ lt) {
+  if (op.type == 1) {
+    uint32_t jt = 0;
+    for (int e = 0; e < op.nlist; ++e)
+      if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
+    if (op.uniform) {
+      const cplx d = lt[op.tab + jt];
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) a[j] = cmul(a[j], d);
+    } else {
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        int jr = 0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += op.regw[c];
+        a[j] = cmul(a[j], lt[op.tab + jt + jr]);
+      }
+    }
+  } else {   // type 3
+    const bool ct = (base & op.tmask) == op.tval;
+    const cplx ph = make_double2(op.m[0], op.m[1]);
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j)
+      if ((((unsigned)j & op.rmask) == op.rval) && ct) a[j] = cmul(a[j], ph);
+  }
+}
+
+// INIT: do not read the shard; start from the uniform-superposition product state instead
+// (amp = val where (index & nonmask) == 0): the init write and the first gate pass become one.
+template <int R, bool INIT>
+__global__ __launch_bounds__(QSV_TPB) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
+                                                   BitIns ins, RegPos rp,
+                                                   const MultiOp* __restrict__ ops, int nops,
+                                                   const cplx* __restrict__ tables, int ntab,
+                                                   uint64_t nonmask, double initval) {
+  extern __shared__ double4 lds_raw[];
+  cplx* lt = reinterpret_cast<cplx*>(lds_raw);
+  for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = tables[i];
+  __syncthreads();
+  const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
+  if (gb + threadIdx.x >= nthreads) return;
+  // address = (uniform 64-bit pointer: shard + block part + register offset) + 32-bit lane part:
+  // the block part and every register offset live in SGPRs, the lane part is ONE VGPR shared by
+  // all 2^R loads and stores (global_load_dwordx4 v, v_off, s[base:base+1]).
+  const uint64_t base_blk = ins_bits(gb, ins);                       // wave-uniform
+  const uint32_t base_thr = (uint32_t)ins_bits((uint64_t)threadIdx.x, ins);
+  const uint64_t base = base_blk | base_thr;
+  cplx* __restrict__ pblk = amp + base_blk;
+  cplx a[1 << R];
+#pragma unroll
+  for (int j = 0; j < (1 << R); ++j) {
+    uint64_t off = 0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
+    if (INIT) a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
+    else a[j] = (pblk + off)[base_thr];
+  }
+  for (int o = 0; o < nops; ++o) {
+    const MultiOp& op = ops[o];
+    if (op.type == 1 || op.type == 3) { multi_diag<R>(a, op, base, lt); continue; }
+    switch (op.bit) {
+      case 0: if (R > 0) multi_2x2_bit<R, 0>(a, op, base, lt); break;
+      case 1: if (R > 1) multi_2x2_bit<R, (R > 1 ? 1 : 0)>(a, op, base, lt); break;
+      case 2: if (R > 2) multi_2x2_bit<R, (R > 2 ? 2 : 0)>(a, op, base, lt); break;
+      case 3: if (R > 3) multi_2x2_bit<R, (R > 3 ? 3 : 0)>(a, op, base, lt); break;
+      case 4: if (R > 4) multi_2x2_bit<R, (R > 4 ? 4 : 0)>(a, op, base, lt); break;
+      default: if (R > 5) multi_2x2_bit<R, (R > 5 ? 5 : 0)>(a, op, base, lt); break;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < (1 << R); ++j) {
+    uint64_t off = 0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
+    (pblk + off)[base_thr] = a[j];
+  }
+}

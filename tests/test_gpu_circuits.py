@@ -190,3 +190,30 @@ def test_full_size_w28_properties(be):
     delta = Z / 2 ** n
     assert abs(ok / 4096 - delta) < 5 * np.sqrt(delta * (1 - delta) / 4096) + 1e-3
     assert all(k[W - 1 - n] == "0" for k in counts)         # classical bit n is never written
+
+
+@pytest.mark.parametrize("multi_r", [0, 1, 2, 3, 4, 5, 6])
+def test_exec_sweep_blocking_random_circuits(be, multi_r):
+    """qsv_exec groups consecutive gates into register-tiled k_multi passes; every register-tile
+    width must reproduce the gate-by-gate result (controls on register / lane / block bits,
+    tables with register-bit selects, X, phases, diagonals)."""
+    from test_host_logic import rand_circuit, oracle_state_of
+    for seed, nq in ((1, 9), (2, 12), (3, 13)):
+        qc = rand_circuit(nq, 150, seed)
+        want = oracle_state_of(qc)
+        for fusion in (0, 2):
+            amp, meta = run_state(be, qc, fusion=fusion, engine_options={"multi_r": multi_r})
+            assert np.abs(amp - want).max() < 1e-12, (seed, nq, fusion)
+    be.run(qc, shots=0, engine_options={"multi_r": 5})          # restore the default
+
+
+@pytest.mark.parametrize("multi_r", [0, 3, 5])
+def test_exec_sweep_blocking_sharded(be, multi_r):
+    from qcmrf_amd import QCMRF
+    C = gs.grid_cliques(2, 3)
+    th = random_theta(cf.model_shape(C)[3], seed=3)
+    for layout in ("auto", "reference"):
+        for fusion in (0, 2):
+            amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, layout=layout, devices=(0,) * 4,
+                                  engine_options={"multi_r": multi_r})
+            assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
