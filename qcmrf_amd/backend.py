@@ -69,18 +69,21 @@ class Job:
 
 
 def _format_keys(values, counts, num_clbits, creg_sizes):
-    """integer outcomes (bit c = classical bit c) -> Qiskit count keys"""
-    out = {}
-    for v, c in zip(values.tolist(), counts.tolist()):
-        s = format(v, "0{}b".format(max(num_clbits, 1)))
-        if creg_sizes and len(creg_sizes) > 1:       # one group per register, last register first
-            parts, hi = [], num_clbits
-            for _, size in reversed(creg_sizes):
-                parts.append(s[num_clbits - hi: num_clbits - hi + size])
-                hi -= size
-            s = " ".join(parts)
-        out[s] = int(c)
-    return out
+    """integer outcomes (bit c = classical bit c) -> Qiskit count keys, vectorised:
+    one (keys x width) matrix of '0'/'1' bytes, decoded once and sliced"""
+    w = max(num_clbits, 1)
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    shifts = np.arange(w - 1, -1, -1, dtype=np.uint64)
+    chars = (((values[:, None] >> shifts) & np.uint64(1)) + np.uint64(48)).astype(np.uint8)
+    text = chars.tobytes().decode("ascii")
+    keys = [text[i * w:(i + 1) * w] for i in range(len(values))]
+    if creg_sizes and len(creg_sizes) > 1:           # one group per register, last register first
+        cuts, hi = [], num_clbits
+        for _, size in reversed(creg_sizes):
+            cuts.append((num_clbits - hi, num_clbits - hi + size))
+            hi -= size
+        keys = [" ".join(k[a:b] for a, b in cuts) for k in keys]
+    return dict(zip(keys, (int(c) for c in counts.tolist())))
 
 
 class QsvBackend:
@@ -101,6 +104,7 @@ class QsvBackend:
         self._engine = None
         self._engine_key = None
         self.last_engine = None
+        self.last_plan = None
         self._engine_factory = None      # test hook only; the default and only shipped engine is libqsv
 
     def name(self):
@@ -131,6 +135,19 @@ class QsvBackend:
         self._engine, self._engine_key = eng, key
         return eng
 
+    def statevector(self):
+        """amplitudes left by the last run, in LOGICAL qubit order (diagnostic; copies 2^W values
+        to the host, so small circuits only).  Index bit q = logical qubit q."""
+        eng, pl = self.last_engine, self.last_plan
+        amp = eng.amplitudes()
+        p = np.arange(amp.size, dtype=np.int64)
+        l = np.zeros_like(p)
+        for q, pos in enumerate(pl.layout):
+            l |= ((p >> pos) & 1) << q
+        out = np.empty_like(amp)
+        out[l] = amp
+        return out
+
     def close(self):
         if self._engine is not None:
             self._engine.close()
@@ -153,7 +170,7 @@ class QsvBackend:
         """ingest + passes + plan only (no GPU): returns (Ingested, Plan)"""
         opts = dict(self.options)
         opts.update(options)
-        ing = _ingest.ingest(circuit)
+        ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1)
         ops = passes.optimise(ing.ops, level=opts["fusion"])
         if ing.global_phase and opts.get("apply_global_phase", True):
             from . import ir

@@ -655,6 +655,8 @@ extern "C" int qsv_apply_mux_1q(qsv_handle* h, int k, const int* ctrls, int t, c
 struct PendingGroup {
   std::vector<LocalOp> ops;
   std::vector<int> targets;       // distinct target bits, in first-use order
+  std::vector<int> selects;       // every table-select bit used by a table op of the group
+  bool simple = true;             // only table ops, and no select bit is a target of the group
   size_t table_cplx = 0;
   bool init = false;              // an init write is waiting to be merged into the pass
   uint64_t nonmask = 0;
@@ -671,22 +673,42 @@ static size_t table_cplx_of(const LocalOp& lo) {
   if (lo.type == 1) return (size_t)1 << lo.list.size();
   return 0;
 }
+static bool has_bit(const std::vector<int>& v, int q) { return std::find(v.begin(), v.end(), q) != v.end(); }
+
+// would the group still be "simple" (table ops only, selects disjoint from targets) with lo added?
+static bool stays_simple(const PendingGroup& g, const LocalOp& lo) {
+  if (!g.simple || lo.type > 1) return false;
+  for (int q : lo.list) if (has_bit(g.targets, q) || q == lo.target) return false;
+  if (lo.target >= 0 && has_bit(g.selects, lo.target)) return false;
+  return true;
+}
 static bool group_fits(const qsv_handle* h, const PendingGroup& g, const LocalOp& lo) {
   size_t nt = g.targets.size();
-  if (lo.target >= 0 && std::find(g.targets.begin(), g.targets.end(), lo.target) == g.targets.end()) ++nt;
-  if ((int)nt > h->opt_multi_r) return false;
-  if (g.table_cplx + table_cplx_of(lo) > 2560) return false;      // 40 KiB of LDS tables
+  if (lo.target >= 0 && !has_bit(g.targets, lo.target)) ++nt;
+  // the general kernel (controls / selects on register bits, masked 2x2) is built for R <= 4
+  const int rmax = stays_simple(g, lo) ? h->opt_multi_r : std::min(h->opt_multi_r, 4);
+  if ((int)nt > rmax) return false;
+  if (g.table_cplx + table_cplx_of(lo) > 2560 - 4) return false;  // 40 KiB of LDS tables
   return g.ops.size() < 64;
+}
+static void group_add(PendingGroup& g, LocalOp&& lo) {
+  g.simple = stays_simple(g, lo);
+  if (lo.target >= 0 && !has_bit(g.targets, lo.target)) g.targets.push_back(lo.target);
+  if (lo.type <= 1) for (int q : lo.list) if (!has_bit(g.selects, q)) g.selects.push_back(q);
+  g.table_cplx += table_cplx_of(lo);
+  g.ops.push_back(std::move(lo));
 }
 
 template <int R>
-static void launch_multi(const qsv_handle* h, const Shard& s, bool init, uint64_t nthreads, const BitIns& ins,
-                         const RegPos& rp, const MultiOp* dops, int nops, const cplx* dtab, int ntab,
-                         uint64_t nonmask, double initval) {
+static void launch_multi(const qsv_handle* h, const Shard& s, bool init, bool simple, uint64_t nthreads, const BitIns& ins,
+                         const RegPos& rp, const MultiOp* dops, const MultiSlot* dslots, int nrounds,
+                         const cplx* dtab, int ntab, uint64_t nonmask, double initval) {
   const dim3 g((unsigned)((nthreads + QSV_TPB - 1) / QSV_TPB));
   const size_t shm = (size_t)std::max(ntab, 1) * sizeof(cplx);
-  if (init) hipLaunchKernelGGL((k_multi<R, true>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, nops, dtab, ntab, nonmask, initval);
-  else      hipLaunchKernelGGL((k_multi<R, false>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, nops, dtab, ntab, nonmask, initval);
+#define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval)
+  if (init) { if (simple) QSV_LM(true, true); else QSV_LM(true, false); }
+  else      { if (simple) QSV_LM(false, true); else QSV_LM(false, false); }
+#undef QSV_LM
 }
 
 static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
@@ -709,10 +731,12 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   // register bits: the targets, padded with free bits >= 6 so every lane keeps >= 8 loads in flight
   std::vector<int> reg = g.targets;
   const int want = std::min(h->L, std::max((int)reg.size(), std::min(3, h->opt_multi_r)));
-  for (int b = std::min(6, h->L - 1); (int)reg.size() < want && b < h->L; ++b)
-    if (std::find(reg.begin(), reg.end(), b) == reg.end()) reg.push_back(b);
+  for (int pass = 0; pass < 2; ++pass) {             // first bits >= 6 that are not table selects, then any
+    for (int b = std::min(6, h->L - 1); (int)reg.size() < want && b < h->L; ++b)
+      if (!has_bit(reg, b) && (pass == 1 || !has_bit(g.selects, b))) reg.push_back(b);
+  }
   for (int b = 0; (int)reg.size() < want && b < h->L; ++b)
-    if (std::find(reg.begin(), reg.end(), b) == reg.end()) reg.push_back(b);
+    if (!has_bit(reg, b)) reg.push_back(b);
   const int R = (int)reg.size();
   RegPos rp;
   memset(&rp, 0, sizeof rp);
@@ -749,9 +773,63 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
       memcpy(mo.m, lo.m, sizeof mo.m);
     }
   }
+  bool simple = true;
+  for (const MultiOp& mo : mops) if (mo.type > 1 || !mo.uniform) simple = false;
+  // rounds of R slots: slot b = [diag ops ...] + optional 2x2 gate on register bit b, program order kept
+  const int NS = std::max(R, 1);
+  std::vector<MultiSlot> slots;
+  std::vector<MultiOp> sorted;
+  sorted.reserve(mops.size());
+  {
+    std::vector<std::vector<int>> slot_ops;          // op indices per slot, diag first then the gate
+    std::vector<int> slot_has;
+    int round = 0, bp = 0;
+    auto ensure = [&](int r) {
+      while ((int)slot_ops.size() < (r + 1) * NS) { slot_ops.emplace_back(); slot_has.push_back(0); }
+    };
+    ensure(0);
+    for (size_t i = 0; i < mops.size(); ++i) {
+      const MultiOp& mo = mops[i];
+      if (mo.type == 1 || mo.type == 3) {
+        if (bp >= NS) { ++round; bp = 0; ensure(round); }
+        slot_ops[round * NS + bp].push_back((int)i);
+      } else {
+        if (mo.bit < bp) { ++round; bp = 0; ensure(round); }
+        slot_ops[round * NS + mo.bit].push_back((int)i);
+        // diagonals parked on an earlier free slot stay ahead of this gate: move them here
+        for (int b = bp; b < mo.bit; ++b) {
+          std::vector<int>& src = slot_ops[round * NS + b];
+          if (!src.empty()) {
+            std::vector<int>& dst = slot_ops[round * NS + mo.bit];
+            dst.insert(dst.begin(), src.begin(), src.end());
+            src.clear();
+          }
+        }
+        slot_has[round * NS + mo.bit] = 1;
+        bp = mo.bit + 1;
+      }
+    }
+    slots.resize(slot_ops.size());
+    MultiOp ident;                                    // simple passes run a gate in every slot
+    memset(&ident, 0, sizeof ident);
+    ident.uniform = 1;
+    ident.tab = (int)(tables.size() / 2);
+    if (simple && R > 0) { const double id4[8] = {1, 0, 0, 0, 0, 0, 1, 0}; tables.insert(tables.end(), id4, id4 + 8); }
+    for (size_t k = 0; k < slot_ops.size(); ++k) {
+      slots[k].first = (int)sorted.size();
+      slots[k].has = slot_has[k];
+      slots[k].ndiag = (int)slot_ops[k].size() - slot_has[k];
+      slots[k].pad = 0;
+      for (int idx : slot_ops[k]) sorted.push_back(mops[idx]);
+      if (simple && R > 0 && !slot_has[k]) { ident.bit = (int)(k % NS); sorted.push_back(ident); }
+    }
+  }
+  const int nrounds = (int)slots.size() / NS;
   void* dops = nullptr;
+  void* dslots = nullptr;
   void* dtab = nullptr;
-  CHK(arena_put(s, mops.data(), mops.size() * sizeof(MultiOp), &dops));
+  CHK(arena_put(s, sorted.data(), sorted.size() * sizeof(MultiOp), &dops));
+  CHK(arena_put(s, slots.data(), slots.size() * sizeof(MultiSlot), &dslots));
   if (tables.empty()) tables.assign(2, 0.0);
   CHK(arena_put(s, tables.data(), tables.size() * sizeof(double), &dtab));
   const int ntab = (int)(tables.size() / 2);
@@ -761,18 +839,18 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   const bool init = g.init;
   const uint64_t nonmask = g.nonmask;
   const double initval = g.initval;
-  const int nops = (int)mops.size();
   const int r = launch(h, s, QSV_K_MULTI, bytes, [&] {
     const MultiOp* o = reinterpret_cast<const MultiOp*>(dops);
+    const MultiSlot* sl = reinterpret_cast<const MultiSlot*>(dslots);
     const cplx* tp = reinterpret_cast<const cplx*>(dtab);
     switch (R) {
-      case 0: launch_multi<0>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      case 1: launch_multi<1>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      case 2: launch_multi<2>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      case 3: launch_multi<3>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      case 4: launch_multi<4>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      case 5: launch_multi<5>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
-      default: launch_multi<6>(h, s, init, nthreads, ins, rp, o, nops, tp, ntab, nonmask, initval); break;
+      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
     }
   });
   g = PendingGroup();
@@ -1174,10 +1252,7 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
             continue;
           }
           if (!group_fits(h, pend[k], lo)) CHK(flush_group(h, s, pend[k]));
-          if (lo.target >= 0 && std::find(pend[k].targets.begin(), pend[k].targets.end(), lo.target) == pend[k].targets.end())
-            pend[k].targets.push_back(lo.target);
-          pend[k].table_cplx += table_cplx_of(lo);
-          pend[k].ops.push_back(std::move(lo));
+          group_add(pend[k], std::move(lo));
         }
         break;
       }

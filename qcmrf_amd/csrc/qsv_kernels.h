@@ -450,15 +450,15 @@ struct MultiOp {
 };
 struct RegPos { int pos[QSV_MULTI_MAXR]; };
 
-template <int R, int B>
+template <int R, int B, bool SIMPLE>
 __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                               const cplx* __restrict__ lt) {
   constexpr int NP = (R > 0) ? (1 << (R - 1)) : 0;
-  if (op.type == 0) {
+  if (SIMPLE || op.type == 0) {
     uint32_t jt = 0;
     for (int e = 0; e < op.nlist; ++e)
       if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
-    if (op.uniform) {
+    if (SIMPLE || op.uniform) {
       const cplx* mp = lt + op.tab + 4 * jt;
       const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
 #pragma unroll
@@ -498,14 +498,14 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
   }
 }
 
-template <int R>
+template <int R, bool SIMPLE>
 __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                            const cplx* __restrict__ lt) {
-  if (op.type == 1) {
+  if (SIMPLE || op.type == 1) {
     uint32_t jt = 0;
     for (int e = 0; e < op.nlist; ++e)
       if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
-    if (op.uniform) {
+    if (SIMPLE || op.uniform) {
       const cplx d = lt[op.tab + jt];
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) a[j] = cmul(a[j], d);
@@ -527,12 +527,37 @@ __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op,
   }
 }
 
+// Schedule: the host lays the gates of a pass out in ROUNDS of R slots.  Slot b of a round holds
+// (optionally) some diagonal ops followed by (optionally) one 2x2-type gate on register bit b.
+// The kernel body is therefore straight-line over b (each 2x2 path instantiated once, guarded by a
+// wave-uniform flag) inside one runtime loop over rounds -- no switch on the target bit, so every
+// amplitude is updated in place in its register (a switch made hipcc copy the whole tile per
+// case: 288 VGPRs at R = 5, spills at R = 6).
+struct MultiSlot { int first; int ndiag; int has; int pad; };   // ops[first .. first+ndiag) diag, then the gate
+
+template <int R, int B, bool SIMPLE>
+__device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __restrict__ ops,
+                                           const MultiSlot* __restrict__ rs, uint64_t base,
+                                           const cplx* __restrict__ lt) {
+  const MultiSlot sl = rs[B];
+  for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, SIMPLE>(a, ops[sl.first + d], base, lt);
+  if constexpr (R > 0) {
+    // SIMPLE passes apply a gate in EVERY slot (the host fills gaps with an identity table):
+    // with no branch around the update, hipcc updates the tile in place instead of keeping an
+    // old and a new copy alive across the merge.
+    if (SIMPLE || sl.has) multi_2x2_bit<R, B, SIMPLE>(a, ops[sl.first + sl.ndiag], base, lt);
+  }
+}
+
 // INIT: do not read the shard; start from the uniform-superposition product state instead
 // (amp = val where (index & nonmask) == 0): the init write and the first gate pass become one.
-template <int R, bool INIT>
-__global__ __launch_bounds__(QSV_TPB) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
+// SIMPLE: every op of the pass is a table op whose select bits are all lane/block bits (the
+// shape of a fused QCMRF circuit): the general paths are compiled out.
+template <int R, bool INIT, bool SIMPLE>
+__global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
                                                    BitIns ins, RegPos rp,
-                                                   const MultiOp* __restrict__ ops, int nops,
+                                                   const MultiOp* __restrict__ ops,
+                                                   const MultiSlot* __restrict__ slots, int nrounds,
                                                    const cplx* __restrict__ tables, int ntab,
                                                    uint64_t nonmask, double initval) {
   extern __shared__ double4 lds_raw[];
@@ -541,9 +566,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_multi(cplx* __restrict__ amp, uint6
   __syncthreads();
   const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
   if (gb + threadIdx.x >= nthreads) return;
-  // address = (uniform 64-bit pointer: shard + block part + register offset) + 32-bit lane part:
-  // the block part and every register offset live in SGPRs, the lane part is ONE VGPR shared by
-  // all 2^R loads and stores (global_load_dwordx4 v, v_off, s[base:base+1]).
+  // address = (uniform 64-bit pointer: shard + block part + register offset) + 32-bit lane part
   const uint64_t base_blk = ins_bits(gb, ins);                       // wave-uniform
   const uint32_t base_thr = (uint32_t)ins_bits((uint64_t)threadIdx.x, ins);
   const uint64_t base = base_blk | base_thr;
@@ -557,17 +580,15 @@ __global__ __launch_bounds__(QSV_TPB) void k_multi(cplx* __restrict__ amp, uint6
     if (INIT) a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
     else a[j] = (pblk + off)[base_thr];
   }
-  for (int o = 0; o < nops; ++o) {
-    const MultiOp& op = ops[o];
-    if (op.type == 1 || op.type == 3) { multi_diag<R>(a, op, base, lt); continue; }
-    switch (op.bit) {
-      case 0: if (R > 0) multi_2x2_bit<R, 0>(a, op, base, lt); break;
-      case 1: if (R > 1) multi_2x2_bit<R, (R > 1 ? 1 : 0)>(a, op, base, lt); break;
-      case 2: if (R > 2) multi_2x2_bit<R, (R > 2 ? 2 : 0)>(a, op, base, lt); break;
-      case 3: if (R > 3) multi_2x2_bit<R, (R > 3 ? 3 : 0)>(a, op, base, lt); break;
-      case 4: if (R > 4) multi_2x2_bit<R, (R > 4 ? 4 : 0)>(a, op, base, lt); break;
-      default: if (R > 5) multi_2x2_bit<R, (R > 5 ? 5 : 0)>(a, op, base, lt); break;
-    }
+  constexpr int NS = (R > 0) ? R : 1;
+  for (int r = 0; r < nrounds; ++r) {
+    const MultiSlot* rs = slots + r * NS;
+    multi_slot<R, 0, SIMPLE>(a, ops, rs, base, lt);
+    if constexpr (R > 1) multi_slot<R, 1, SIMPLE>(a, ops, rs, base, lt);
+    if constexpr (R > 2) multi_slot<R, 2, SIMPLE>(a, ops, rs, base, lt);
+    if constexpr (R > 3) multi_slot<R, 3, SIMPLE>(a, ops, rs, base, lt);
+    if constexpr (R > 4) multi_slot<R, 4, SIMPLE>(a, ops, rs, base, lt);
+    if constexpr (R > 5) multi_slot<R, 5, SIMPLE>(a, ops, rs, base, lt);
   }
 #pragma unroll
   for (int j = 0; j < (1 << R); ++j) {

@@ -55,17 +55,16 @@ class Op:
     __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
                  "a", "b", "label")
 
-    def __init__(self, kind, **kw):
+    def __init__(self, kind, target=None, ctrls=(), vals=(), qubits=(), mat=None, table=None, mats=None,
+                 angle=0.0, mask=0, a=(), b=(), label=""):
         self.kind = kind
-        self.target = None
-        self.ctrls, self.vals, self.qubits = (), (), ()
-        self.mat = self.table = self.mats = None
-        self.angle = 0.0
-        self.mask = 0
-        self.a = self.b = ()
-        self.label = ""
-        for k, v in kw.items():
-            setattr(self, k, v)
+        self.target = target
+        self.ctrls, self.vals, self.qubits = ctrls, vals, qubits
+        self.mat, self.table, self.mats = mat, table, mats
+        self.angle = angle
+        self.mask = mask
+        self.a, self.b = a, b
+        self.label = label
 
     def support(self):
         """every logical qubit the op reads or writes"""

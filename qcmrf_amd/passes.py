@@ -60,55 +60,78 @@ def _monomial_ok(op):
 class _Window:
     def __init__(self):
         self.q = []                       # window qubits; window bit b <-> logical qubit q[b]
+        self.pos = {}                     # logical qubit -> window bit
         self.perm = np.zeros(1, dtype=np.int64)
         self.phase = np.ones(1, dtype=np.complex128)
         self.ops = []                     # source ops absorbed so far
+        self.is_id = True                 # perm is the identity right now
         self.mark = 0                     # ops[:mark] compose to the diagonal ``mark_phase``
-        self.mark_phase = np.ones(1, dtype=np.complex128)
+        self.mark_phase = self.phase
         self.mark_nq = 0
 
     def bit(self, q):
-        if q not in self.q:
+        b = self.pos.get(q)
+        if b is None:
+            b = self.pos[q] = len(self.q)
             self.q.append(q)
             n = self.perm.size
             self.perm = np.concatenate([self.perm, self.perm + n])
             self.phase = np.concatenate([self.phase, self.phase])
-        return self.q.index(q)
+        return b
+
+    def _fire(self, idx, qubits, vals):
+        cmask = cval = 0
+        for q, v in zip(qubits, vals):
+            b = self.bit(q)
+            cmask |= 1 << b
+            cval |= v << b
+        return cmask, cval
 
     def add(self, op):
-        bits = [self.bit(q) for q in op.support()]
-        idx = self.perm                                  # current images
-        if op.kind == "x" or op.kind == "u":
-            cb, tb = bits[:-1], bits[-1]
-            fire = np.ones(idx.shape, dtype=bool)
-            for b, v in zip(cb, op.vals):
-                fire &= ((idx >> b) & 1) == v
-            if op.kind == "x":
-                self.perm = np.where(fire, idx ^ (1 << tb), idx)
+        k = op.kind
+        if k == "x" or k == "u":
+            tb = self.bit(op.target)
+            cmask, cval = self._fire(None, op.ctrls, op.vals)
+            idx = self.perm                              # current images (after any growth)
+            if k == "x":
+                if cmask:
+                    self.perm = idx ^ (((idx & cmask) == cval) << tb)
+                else:
+                    self.perm = idx ^ (1 << tb)
+                self.is_id = False
             else:
                 m = op.mat
                 tv = (idx >> tb) & 1
-                if m[0, 0] != 0:                         # diagonal 2x2
-                    ph = np.where(tv == 0, m[0, 0], m[1, 1])
+                anti = m[0, 0] == 0
+                ph = np.where(tv == 0, m[1, 0], m[0, 1]) if anti else np.where(tv == 0, m[0, 0], m[1, 1])
+                if cmask:
+                    fire = (idx & cmask) == cval
                     self.phase = self.phase * np.where(fire, ph, 1.0)
-                else:                                    # anti-diagonal: |0> -> m10 |1>, |1> -> m01 |0>
-                    ph = np.where(tv == 0, m[1, 0], m[0, 1])
-                    self.phase = self.phase * np.where(fire, ph, 1.0)
-                    self.perm = np.where(fire, idx ^ (1 << tb), idx)
-        elif op.kind == "mcphase":
-            fire = np.ones(idx.shape, dtype=bool)
-            for b, v in zip(bits, op.vals):
-                fire &= ((idx >> b) & 1) == v
-            self.phase = self.phase * np.where(fire, np.exp(1j * op.angle), 1.0)
+                    if anti:
+                        self.perm = idx ^ (fire << tb)
+                else:
+                    self.phase = self.phase * ph
+                    if anti:
+                        self.perm = idx ^ (1 << tb)
+                if anti:
+                    self.is_id = False
+        elif k == "mcphase":
+            cmask, cval = self._fire(None, op.qubits, op.vals)
+            idx = self.perm
+            self.phase = self.phase * np.where((idx & cmask) == cval, np.exp(1j * op.angle), 1.0)
         else:                                            # diag
-            j = np.zeros(idx.shape, dtype=np.int64)
-            for k, b in enumerate(bits):
-                j |= ((idx >> b) & 1) << k
+            bits = [self.bit(q) for q in op.qubits]
+            idx = self.perm
+            j = (idx >> bits[0]) & 1
+            for e in range(1, len(bits)):
+                j |= ((idx >> bits[e]) & 1) << e
             self.phase = self.phase * op.table[j]
         self.ops.append(op)
-        if np.array_equal(self.perm, np.arange(self.perm.size)):
+        if not self.is_id and (k == "x" or k == "u"):
+            self.is_id = bool((self.perm == np.arange(self.perm.size)).all())
+        if self.is_id:
             self.mark = len(self.ops)
-            self.mark_phase = self.phase.copy()
+            self.mark_phase = self.phase
             self.mark_nq = len(self.q)
 
 
@@ -161,7 +184,7 @@ def fuse_monomial(ops, kmax=10):
             continue
         if win is None:
             win = _Window()
-        newq = [q for q in op.support() if q not in win.q]
+        newq = [q for q in op.support() if q not in win.pos]
         if not win.ops and len(newq) > kmax:              # a single gate wider than any window
             win = None
             out.append(op)

@@ -51,10 +51,20 @@ def _remap(op, lay):
     return o
 
 
+LANE_BITS = 6      # address bits 0..5 are the lane id of a wavefront load (1 KiB contiguous)
+
+
 def choose_layout(ops, n_qubits, n_shards, layout="auto"):
+    """layout[logical] = physical.
+
+    auto, measured on MI355X (profiles/r01_multi_bits_W28.json): a k_multi pass streams at
+    5.3-5.7 TB/s when its target bits sit just above the lane bits (6..~16) and drops to
+    3.7-4.4 TB/s when they are adjacent bits around 17..24 (strides of 2-256 MiB camp on the same
+    HBM channels).  So: never-dense qubits (pure selects/controls) take the lane bits and the top
+    (shard) bits, dense targets are packed upward from bit 6 in order of first use."""
     g = n_shards.bit_length() - 1
     L = n_qubits - g
-    if g == 0 or layout == "reference":
+    if layout == "reference":
         return list(range(n_qubits))
     if layout != "auto":
         raise ValueError("layout must be 'auto' or 'reference', not %r" % (layout,))
@@ -75,9 +85,13 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto"):
         return (0 if first == never else 1, 0 if (uniform >> q) & 1 else 1, -first, dense_count[q], -q)
 
     shard_q = sorted(sorted(range(n_qubits), key=badness)[:g])
-    local_q = [q for q in range(n_qubits) if q not in shard_q]
+    rest = [q for q in range(n_qubits) if q not in shard_q]
+    dense = sorted((q for q in rest if q in dense_first), key=lambda q: (dense_first[q], q))
+    quiet = [q for q in rest if q not in dense_first]
+    n_lane = min(LANE_BITS, max(0, L - len(dense)), len(quiet))
+    order = quiet[:n_lane] + dense + quiet[n_lane:]          # physical 0, 1, 2, ...
     lay = [0] * n_qubits
-    for p, q in enumerate(local_q):
+    for p, q in enumerate(order):
         lay[q] = p
     for p, q in enumerate(shard_q):
         lay[q] = L + p
