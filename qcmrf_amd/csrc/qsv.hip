@@ -109,6 +109,7 @@ struct Shard {
   cplx* xbuf[2] = {nullptr, nullptr};
   size_t xbuf_amps = 0;
   int n_cu = 256;
+  uint64_t zmask = 0;            // zero tracking: local bits known |0>; memory with such a bit set is unwritten
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
 };
@@ -129,6 +130,7 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = 0;
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
+  int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
 };
 
@@ -414,6 +416,7 @@ extern "C" int qsv_init_uniform(qsv_handle* h, uint64_t qubit_mask) {
     const uint64_t hi = (uint64_t)s.index << h->L;
     const double v = (hi & ~qubit_mask) ? 0.0 : val;
     const uint64_t nonmask = ~qubit_mask & lmask;
+    s.zmask = 0;
     CHK(launch(h, s, QSV_K_INIT, 16.0 * (double)n, [&] {
       hipLaunchKernelGGL(k_init, dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream,
                          s.amp, n, nonmask, v);
@@ -702,13 +705,26 @@ static void group_add(PendingGroup& g, LocalOp&& lo) {
 template <int R>
 static void launch_multi(const qsv_handle* h, const Shard& s, bool init, bool simple, uint64_t nthreads, const BitIns& ins,
                          const RegPos& rp, const MultiOp* dops, const MultiSlot* dslots, int nrounds,
-                         const cplx* dtab, int ntab, uint64_t nonmask, double initval) {
+                         const cplx* dtab, int ntab, uint64_t nonmask, double initval, unsigned zreg) {
   const dim3 g((unsigned)((nthreads + QSV_TPB - 1) / QSV_TPB));
   const size_t shm = (size_t)std::max(ntab, 1) * sizeof(cplx);
-#define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval)
+#define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval, zreg)
   if (init) { if (simple) QSV_LM(true, true); else QSV_LM(true, false); }
   else      { if (simple) QSV_LM(false, true); else QSV_LM(false, false); }
 #undef QSV_LM
+}
+
+// zero tracking: write the zeros that were only implied so far
+static int materialize(qsv_handle* h, Shard& s) {
+  if (!s.zmask) return QSV_OK;
+  const uint64_t n = amps_local(h);
+  const uint64_t zm = s.zmask;
+  s.zmask = 0;
+  CHK(shard_set(s));
+  const int nz = __builtin_popcountll(zm);
+  return launch(h, s, QSV_K_INIT, 16.0 * ((double)n - (double)(n >> nz)), [&] {
+    hipLaunchKernelGGL(k_fill_zero, dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, n, zm);
+  });
 }
 
 static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
@@ -716,6 +732,7 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   CHK(shard_set(s));
   if (g.ops.empty()) {
     if (g.init) {
+      s.zmask = 0;
       CHK(launch(h, s, QSV_K_INIT, 16.0 * (double)n, [&] {
         hipLaunchKernelGGL(k_init, dim3(grid_for(h, s, n, QSV_TPB * 4)), dim3(QSV_TPB), 0, s.stream, s.amp, n, g.nonmask, g.initval);
       }));
@@ -724,6 +741,7 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
     return QSV_OK;
   }
   if (g.ops.size() == 1 && !g.init) {
+    CHK(materialize(h, s));
     const int r = run_single(h, s, g.ops[0]);
     g = PendingGroup();
     return r;
@@ -733,7 +751,7 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   const int want = std::min(h->L, std::max((int)reg.size(), std::min(3, h->opt_multi_r)));
   for (int pass = 0; pass < 2; ++pass) {             // first bits >= 6 that are not table selects, then any
     for (int b = std::min(6, h->L - 1); (int)reg.size() < want && b < h->L; ++b)
-      if (!has_bit(reg, b) && (pass == 1 || !has_bit(g.selects, b))) reg.push_back(b);
+      if (!has_bit(reg, b) && (pass == 1 || (!has_bit(g.selects, b) && !((s.zmask >> b) & 1ull)))) reg.push_back(b);
   }
   for (int b = 0; (int)reg.size() < want && b < h->L; ++b)
     if (!has_bit(reg, b)) reg.push_back(b);
@@ -741,7 +759,18 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   RegPos rp;
   memset(&rp, 0, sizeof rp);
   for (int c = 0; c < R; ++c) rp.pos[c] = reg[c];
-  const BitIns ins = make_ins(reg);
+  // zero tracking: register bits still known |0> are not read; known-zero bits outside the tile
+  // stay zero, so only the subspace where they are 0 is enumerated at all
+  uint64_t regmask = 0;
+  for (int q : reg) regmask |= 1ull << q;
+  const uint64_t zin = s.zmask, zout = zin & ~regmask;
+  unsigned zreg = 0;
+  for (int c = 0; c < R; ++c) if ((zin >> reg[c]) & 1ull) zreg |= 1u << c;
+  std::vector<int> inspos = reg;
+  for (int b = 0; b < h->L; ++b) if ((zout >> b) & 1ull) inspos.push_back(b);
+  const int nzout = __builtin_popcountll(zout);
+  s.zmask = zout;
+  const BitIns ins = make_ins(inspos);
   auto reg_index = [&](int q) -> int {
     for (int c = 0; c < R; ++c) if (reg[c] == q) return c;
     return -1;
@@ -833,8 +862,10 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   if (tables.empty()) tables.assign(2, 0.0);
   CHK(arena_put(s, tables.data(), tables.size() * sizeof(double), &dtab));
   const int ntab = (int)(tables.size() / 2);
-  const uint64_t nthreads = n >> R;
-  const double bytes = (g.init ? 16.0 : 32.0) * (double)n;
+  const uint64_t nthreads = n >> (R + nzout);
+  const double n_written = (double)(n >> nzout);
+  const double n_read = g.init ? 0.0 : (double)(n >> (nzout + __builtin_popcount(zreg)));
+  const double bytes = 16.0 * (n_written + n_read);
   h->stats.fused_gates += g.ops.size();
   const bool init = g.init;
   const uint64_t nonmask = g.nonmask;
@@ -844,13 +875,13 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
     const MultiSlot* sl = reinterpret_cast<const MultiSlot*>(dslots);
     const cplx* tp = reinterpret_cast<const cplx*>(dtab);
     switch (R) {
-      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
-      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval); break;
+      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
     }
   });
   g = PendingGroup();
@@ -1234,6 +1265,7 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
           pend[k].init = true;
           pend[k].initval = (hi & ~mask) ? 0.0 : val;
           pend[k].nonmask = ~mask & (amps_local(h) - 1);
+          h->shards[k].zmask = h->opt_zero_tracking ? pend[k].nonmask : 0ull;
         }
         break;
       }
@@ -1248,6 +1280,7 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
           if (!resolve_gate(h, s, o.kind, o.n, o.qubits, o.vals, o.target, d, o.angle, lo)) continue;
           if (!groupable(h, lo)) {
             CHK(flush_group(h, s, pend[k]));
+            CHK(materialize(h, s));
             CHK(run_single(h, s, lo));
             continue;
           }
@@ -1258,18 +1291,22 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
       }
       case QSV_OP_KQ:
         CHK(flush_all());
+        for (Shard& s : h->shards) CHK(materialize(h, s));
         CHK(need(2ull << (2 * o.n)));
         CHK(qsv_apply_kq(h, o.n, o.qubits, d));
         break;
       case QSV_OP_SWAP:
         CHK(flush_all());
+        for (Shard& s : h->shards) CHK(materialize(h, s));
         CHK(qsv_swap_layout(h, o.n, o.qubits, o.vals));
         break;
       default:
         return fail(QSV_E_BADARG, "op %d: unknown kind %d", i, o.kind);
     }
   }
-  return flush_all();
+  CHK(flush_all());
+  for (Shard& s : h->shards) CHK(materialize(h, s));
+  return QSV_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1319,6 +1356,7 @@ extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "unroll")) h->opt_unroll = value;
   else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
   else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "zero_tracking")) h->opt_zero_tracking = value != 0;
   else if (!strcmp(name, "multi_r")) { if (value < 0 || value > QSV_MULTI_MAXR) return fail(QSV_E_BADARG, "multi_r out of range"); h->opt_multi_r = value; }
   else if (!strcmp(name, "exchange_chunk_log2")) { if (value < 4 || value > 32) return fail(QSV_E_BADARG, "exchange_chunk_log2 out of range"); h->opt_xchunk = 1ull << value; }
   else return fail(QSV_E_BADARG, "unknown option %s", name);

@@ -559,7 +559,12 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
                                                    const MultiOp* __restrict__ ops,
                                                    const MultiSlot* __restrict__ slots, int nrounds,
                                                    const cplx* __restrict__ tables, int ntab,
-                                                   uint64_t nonmask, double initval) {
+                                                   uint64_t nonmask, double initval,
+                                                   unsigned int zreg) {
+  // zreg (zero tracking): register bits whose qubit is still known to be |0> on entry -- every
+  // amplitude with such a bit set is zero by construction and is not read (memory there may be
+  // unwritten).  `ins` then also holds the known-zero NON-register bits, so only the populated
+  // subspace is enumerated at all.
   extern __shared__ double4 lds_raw[];
   cplx* lt = reinterpret_cast<cplx*>(lds_raw);
   for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = tables[i];
@@ -578,6 +583,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
 #pragma unroll
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
     if (INIT) a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
+    else if ((unsigned)j & zreg) a[j] = make_double2(0.0, 0.0);
     else a[j] = (pblk + off)[base_thr];
   }
   constexpr int NS = (R > 0) ? R : 1;
@@ -597,4 +603,11 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
     (pblk + off)[base_thr] = a[j];
   }
+}
+
+// zero tracking epilogue: amplitudes with any bit of zmask set were never written; make them 0
+__global__ __launch_bounds__(QSV_TPB) void k_fill_zero(cplx* __restrict__ amp, uint64_t n, uint64_t zmask) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t i = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; i < n; i += stride)
+    if (i & zmask) amp[i] = make_double2(0.0, 0.0);
 }

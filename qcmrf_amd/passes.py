@@ -29,12 +29,22 @@ _H = ir.FIXED_1Q["h"]
 
 
 def fold_init(ops):
-    """[init(mask)] + remaining ops.  Only plain H on a qubit nothing has touched yet is folded."""
+    """[init(mask)] + remaining ops.  A plain H on a qubit nothing has touched yet is folded into
+    the initial state -- but only if the qubit is never a dense target afterwards (it then stays
+    a pure select in uniform superposition, like the MRF variable qubits, QCMRF.py:204-205).
+    An ancilla's opening H (QCMRF.py:231) is NOT folded: it fuses into the ancilla's own
+    multiplexer anyway, and keeping the ancilla in |0> until then is what lets the engine skip
+    the still-empty part of the vector (zero tracking)."""
+    last_dense = {}
+    for k, op in enumerate(ops):
+        for q in op.dense_targets():
+            last_dense[q] = k
     mask = 0
     touched = set()
     rest = []
-    for op in ops:
-        if op.kind == "u" and not op.ctrls and op.target not in touched and np.array_equal(op.mat, _H):
+    for k, op in enumerate(ops):
+        if (op.kind == "u" and not op.ctrls and op.target not in touched and last_dense.get(op.target) == k
+                and np.array_equal(op.mat, _H)):
             mask |= 1 << op.target          # commutes past every deferred op: none of them touches it
             touched.add(op.target)
             continue

@@ -87,9 +87,13 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto"):
     shard_q = sorted(sorted(range(n_qubits), key=badness)[:g])
     rest = [q for q in range(n_qubits) if q not in shard_q]
     dense = sorted((q for q in rest if q in dense_first), key=lambda q: (dense_first[q], q))
-    quiet = [q for q in rest if q not in dense_first]
-    n_lane = min(LANE_BITS, max(0, L - len(dense)), len(quiet))
-    order = quiet[:n_lane] + dense + quiet[n_lane:]          # physical 0, 1, 2, ...
+    # never-dense qubits: those in uniform superposition make good lane bits (every amplitude is
+    # populated); those that stay |0> for the whole circuit (the AND scratch qubit, QCMRF.py:219)
+    # go to the top so that the provably-zero half of the shard is one contiguous block
+    quiet_u = [q for q in rest if q not in dense_first and (uniform >> q) & 1]
+    quiet_z = [q for q in rest if q not in dense_first and not (uniform >> q) & 1]
+    n_lane = min(LANE_BITS, max(0, L - len(dense)), len(quiet_u))
+    order = quiet_u[:n_lane] + dense + quiet_u[n_lane:] + quiet_z   # physical 0, 1, 2, ...
     lay = [0] * n_qubits
     for p, q in enumerate(order):
         lay[q] = p

@@ -191,8 +191,9 @@ def test_full_size_w28_properties(be):
     assert all(k[W - 1 - n] == "0" for k in counts)         # classical bit n is never written
 
 
+@pytest.mark.parametrize("zero_tracking", [0, 1])
 @pytest.mark.parametrize("multi_r", [0, 1, 2, 3, 4, 5, 6])
-def test_exec_sweep_blocking_random_circuits(be, multi_r):
+def test_exec_sweep_blocking_random_circuits(be, multi_r, zero_tracking):
     """qsv_exec groups consecutive gates into register-tiled k_multi passes; every register-tile
     width must reproduce the gate-by-gate result (controls on register / lane / block bits,
     tables with register-bit selects, X, phases, diagonals)."""
@@ -201,18 +202,39 @@ def test_exec_sweep_blocking_random_circuits(be, multi_r):
         qc = rand_circuit(nq, 150, seed)
         want = oracle_state_of(qc)
         for fusion in (0, 2):
-            amp, meta = run_state(be, qc, fusion=fusion, engine_options={"multi_r": multi_r})
+            amp, meta = run_state(be, qc, fusion=fusion,
+                                  engine_options={"multi_r": multi_r, "zero_tracking": zero_tracking})
             assert np.abs(amp - want).max() < 1e-12, (seed, nq, fusion)
-    be.run(qc, shots=0, engine_options={"multi_r": 5})          # restore the default
+    be.run(qc, shots=0, engine_options={"multi_r": 5, "zero_tracking": 0})          # restore the defaults
 
 
+@pytest.mark.parametrize("zero_tracking", [0, 1])
 @pytest.mark.parametrize("multi_r", [0, 3, 5])
-def test_exec_sweep_blocking_sharded(be, multi_r):
+def test_exec_sweep_blocking_sharded(be, multi_r, zero_tracking):
     from qcmrf_amd import QCMRF
     C = gs.grid_cliques(2, 3)
     th = random_theta(cf.model_shape(C)[3], seed=3)
     for layout in ("auto", "reference"):
         for fusion in (0, 2):
             amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, layout=layout, devices=(0,) * 4,
-                                  engine_options={"multi_r": multi_r})
+                                  engine_options={"multi_r": multi_r, "zero_tracking": zero_tracking})
             assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+    be.run(QCMRF(C, th), shots=0, devices=(0,) * 4, engine_options={"multi_r": 5, "zero_tracking": 0})
+
+
+def test_zero_tracking_qcmrf_all_graphs(be, models):
+    """opt-in zero tracking (skip the provably-zero part of the shard) is exact"""
+    from qcmrf_amd import QCMRF
+    for j, C in enumerate(models["0.5"]["GRAPHS"]):
+        th = models["0.5"]["THETAS"][str(j)][5]
+        for fusion in (0, 1, 2):
+            amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, engine_options={"zero_tracking": 1})
+            assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+    C = gs.chain_cliques(10)
+    th = random_theta(36)
+    amp, meta = run_state(be, QCMRF(C, th), engine_options={"zero_tracking": 1})
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+    counts = be.run(QCMRF(C, th), shots=2000, seed_simulator=3).result().get_counts()
+    p = cf.probabilities(C, th)
+    assert all(p[int(k, 2)] > 0 for k in counts)
+    be.run(QCMRF(C, th), shots=0, engine_options={"zero_tracking": 0})

@@ -68,7 +68,7 @@ def test_fused_program_shape():
     assert kinds == ["init"] + ["mux"] * 15                  # one sweep per clique
     assert all(len(o.ctrls) == 3 for o in pl.ops[1:])       # two variables + the AND scratch qubit
     ing, pl = be.compile(qc, fusion=1)
-    assert [o.kind for o in pl.ops] == ["init"] + ["diag", "u"] * 15
+    assert [o.kind for o in pl.ops] == ["init"] + ["u", "diag", "u"] * 15      # H . diag . H per clique
     ing, pl = be.compile(qc, fusion=0)
     assert len(pl.ops) == 1 + 12 + 15 * 60
 
