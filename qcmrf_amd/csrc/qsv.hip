@@ -130,6 +130,7 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = 0;
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
+  int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
 };
@@ -896,6 +897,14 @@ static void launch_kq(const qsv_handle* h, const Shard& s, uint64_t ngroups, con
                      s.amp, ngroups, ins, offs, u);
 }
 
+template <int K>
+static void launch_kq_mfma(const qsv_handle* h, const Shard& s, uint64_t nbatch, const BitIns& ins,
+                           const KqOffs& offs, const double* ur, const double* ui) {
+  // every wave keeps U in registers; give each at least ~8 batches to amortise loading it
+  const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((nbatch + 31) / 32, (uint64_t)s.n_cu * 64));
+  hipLaunchKernelGGL((k_kq_mfma<K>), dim3((unsigned)blocks), dim3(QSV_TPB), 0, s.stream, s.amp, nbatch, ins, offs, ur, ui);
+}
+
 extern "C" int qsv_apply_kq(qsv_handle* h, int k, const int* qubits, const double* u) {
   if (!h) return fail(QSV_E_BADARG, "NULL handle");
   if (k < 1 || k > QSV_MAX_KQ || !qubits || !u) return fail(QSV_E_BADARG, "kq needs 1..%d qubits and a matrix", QSV_MAX_KQ);
@@ -905,6 +914,44 @@ extern "C" int qsv_apply_kq(qsv_handle* h, int k, const int* qubits, const doubl
       return fail(QSV_E_UNSUPPORTED, "qubit %d of a dense gate is a shard bit (local qubits: %d); qsv_swap_layout it first", qubits[b], h->L);
   if (h->L < k) return fail(QSV_E_BADARG, "dense %d-qubit gate on %d local qubits", k, h->L);
   const uint64_t n = amps_local(h);
+
+  // matrix-core path: K = 4, 5 natively; K = 3 embedded as I (x) U on one extra (free) qubit
+  const int km = k >= 4 ? k : 4;
+  if (h->opt_kq_mfma && k >= 3 && h->L - km >= 3) {
+    std::vector<int> q(qubits, qubits + k);
+    if (k == 3)
+      for (int b = 0; b < h->L; ++b)
+        if (std::find(q.begin(), q.end(), b) == q.end()) { q.push_back(b); break; }
+    const int D = 1 << km, d = 1 << k;
+    std::vector<double> ri(2 * (size_t)D * D, 0.0);       // Ur then Ui, row-major D x D
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) {
+        if ((r >> k) != (c >> k)) continue;                // block diagonal in the padding bit
+        const double* e = u + 2 * ((size_t)(r & (d - 1)) * d + (c & (d - 1)));
+        ri[(size_t)r * D + c] = e[0];
+        ri[(size_t)D * D + (size_t)r * D + c] = e[1];
+      }
+    KqOffs offs;
+    memset(&offs, 0, sizeof offs);
+    for (int j = 0; j < D; ++j)
+      for (int b = 0; b < km; ++b)
+        if ((j >> b) & 1) offs.off[j] |= 1ull << q[b];
+    const BitIns ins = make_ins(q);
+    const uint64_t nbatch = (n >> km) / 8;
+    for (Shard& s : h->shards) {
+      CHK(shard_set(s));
+      void* dtab = nullptr;
+      CHK(arena_put(s, ri.data(), ri.size() * sizeof(double), &dtab));
+      const double* ur = reinterpret_cast<const double*>(dtab);
+      const double* ui = ur + (size_t)D * D;
+      CHK(launch(h, s, QSV_K_KQ, 32.0 * (double)n, [&] {
+        if (km == 4) launch_kq_mfma<4>(h, s, nbatch, ins, offs, ur, ui);
+        else         launch_kq_mfma<5>(h, s, nbatch, ins, offs, ur, ui);
+      }));
+    }
+    return QSV_OK;
+  }
+
   const uint64_t ngroups = n >> k;
   KqOffs offs;
   memset(&offs, 0, sizeof offs);
@@ -1356,6 +1403,7 @@ extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "unroll")) h->opt_unroll = value;
   else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
   else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "kq_mfma")) h->opt_kq_mfma = value != 0;
   else if (!strcmp(name, "zero_tracking")) h->opt_zero_tracking = value != 0;
   else if (!strcmp(name, "multi_r")) { if (value < 0 || value > QSV_MULTI_MAXR) return fail(QSV_E_BADARG, "multi_r out of range"); h->opt_multi_r = value; }
   else if (!strcmp(name, "exchange_chunk_log2")) { if (value < 4 || value > 32) return fail(QSV_E_BADARG, "exchange_chunk_log2 out of range"); h->opt_xchunk = 1ull << value; }

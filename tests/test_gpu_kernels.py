@@ -124,11 +124,15 @@ def test_mux(lib, n):
         assert np.abs(e.amplitudes() - ref).max() < TOL
 
 
-@pytest.mark.parametrize("n,k", [(5, 1), (6, 2), (9, 3), (12, 4), (13, 5)])
-def test_kq_dense(lib, n, k):
+@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("n,k", [(5, 1), (6, 2), (7, 3), (9, 3), (8, 4), (12, 4), (8, 5), (13, 5), (16, 5)])
+def test_kq_dense(lib, n, k, mfma):
+    """dense k-qubit unitary: VALU register kernel (mfma=0) and the f64 matrix-core kernel
+    (mfma=1, k >= 3) against the numpy oracle, targets in random order at random positions"""
     rs = np.random.RandomState(n * 10 + k)
     ref = rand_state(n, 17)
     with lib.Engine(n) as e:
+        e.set_option("kq_mfma", mfma)
         e.set_amplitudes(0, ref)
         for trial in range(4):
             qs = rs.permutation(n)[:k].tolist()
