@@ -89,7 +89,8 @@ def _format_keys(values, counts, num_clbits, creg_sizes):
 class QsvBackend:
     """MI355X statevector backend.  Options (constructor or per ``run`` call):
 
-    fusion      0 gate by gate | 1 + init/diagonal fusion | 2 + multiplexer fusion (default)
+    fusion      0 gate by gate | 1 + init/diagonal fusion | 2 + multiplexer fusion |
+                3 + dense <=5-qubit windows with structure recovery (default)
     layout      'auto' (exchange-free where possible) | 'reference' (qubit q on index bit q)
     devices     HIP device id per shard owned by this process (repeat an id for virtual shards)
     comm        process group for one-process-per-GPU launches (qcmrf_amd.comm)
@@ -98,7 +99,7 @@ class QsvBackend:
 
     def __init__(self, name="qasm_simulator", **options):
         self._name = name
-        self.options = {"fusion": 2, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
+        self.options = {"fusion": 3, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
                         "profile": False, "engine_options": None}
         self.options.update(options)
         self._engine = None

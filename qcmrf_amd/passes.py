@@ -25,32 +25,81 @@ from .ir import Op
 # --------------------------------------------------------------------------------------------
 # pass 1
 # --------------------------------------------------------------------------------------------
-_H = ir.FIXED_1Q["h"]
 
 
-def fold_init(ops):
-    """[init(mask)] + remaining ops.  A plain H on a qubit nothing has touched yet is folded into
-    the initial state -- but only if the qubit is never a dense target afterwards (it then stays
-    a pure select in uniform superposition, like the MRF variable qubits, QCMRF.py:204-205).
-    An ancilla's opening H (QCMRF.py:231) is NOT folded: it fuses into the ancilla's own
-    multiplexer anyway, and keeping the ancilla in |0> until then is what lets the engine skip
-    the still-empty part of the vector (zero tracking)."""
-    last_dense = {}
-    for k, op in enumerate(ops):
-        for q in op.dense_targets():
-            last_dense[q] = k
-    mask = 0
-    touched = set()
-    rest = []
-    for k, op in enumerate(ops):
-        if (op.kind == "u" and not op.ctrls and op.target not in touched and last_dense.get(op.target) == k
-                and np.array_equal(op.mat, _H)):
-            mask |= 1 << op.target          # commutes past every deferred op: none of them touches it
-            touched.add(op.target)
+_X2 = np.array([[0, 1], [1, 0]], dtype=np.complex128)
+SQH = 1.0 / np.sqrt(2.0)
+
+
+def _as_1q(op):
+    """(qubit, 2x2) if op is an uncontrolled one-qubit gate, else None"""
+    if op.kind == "u" and not op.ctrls:
+        return op.target, op.mat
+    if op.kind == "x" and not op.ctrls:
+        return op.target, _X2
+    if op.kind == "diag" and len(op.qubits) == 1:
+        return op.qubits[0], np.diag(op.table)
+    if op.kind == "mcphase" and len(op.qubits) == 1:
+        d = np.ones(2, dtype=np.complex128)
+        d[op.vals[0]] = np.exp(1j * op.angle)
+        return op.qubits[0], np.diag(d)
+    return None
+
+
+def split_leading(ops):
+    """lead[q] = product of the uncontrolled one-qubit gates that are the first things to touch q
+    (``rz sx rz`` of a lowered H, or a literal H); rest = everything else, order kept."""
+    lead, closed, rest = {}, set(), []
+    for op in ops:
+        one = _as_1q(op)
+        if one is not None and one[0] not in closed:
+            q, m = one
+            lead[q] = m @ lead[q] if q in lead else np.array(m, dtype=np.complex128)
             continue
-        touched.update(op.support())
+        closed.update(op.support())
         rest.append(op)
-    return [ir.op_init(mask)] + rest
+    return lead, rest
+
+
+def _is_hlike(m):
+    return abs(abs(m[0, 0]) - SQH) < 1e-15 and abs(abs(m[1, 0]) - SQH) < 1e-15
+
+
+def fold_init(ops, hold=None):
+    """[init(mask)] + remaining ops.
+
+    A leading one-qubit gate that maps |0> to an equal-weight superposition (H, or its lowered
+    form) is folded into the initial state: the qubit goes into the uniform ``init`` mask, its
+    relative phase becomes a one-qubit diagonal, its common phase a global phase.  Qubits in
+    ``hold`` are exempt.  Default ``hold``: every qubit that is a dense target later on -- the MRF
+    variable qubits fold (QCMRF.py:204-205), an ancilla's opening H (QCMRF.py:231) does not: it
+    fuses into the ancilla's own multiplexer anyway, and keeping the ancilla in |0> until then is
+    what lets the engine skip the still-empty part of the vector (zero tracking)."""
+    lead, rest = split_leading(ops)
+    if hold is None:
+        hold = set(q for op in rest for q in op.dense_targets())
+    fold = set(q for q, m in lead.items() if q not in hold and _is_hlike(m))
+    mask, gphase = 0, 1.0 + 0.0j
+    front = []
+    for q in sorted(fold):
+        m = lead[q]
+        mask |= 1 << q
+        a, b = m[0, 0] / abs(m[0, 0]), m[1, 0] / abs(m[1, 0])
+        gphase *= a
+        if abs(b / a - 1.0) > 1e-15:
+            front.append(ir.op_diag([q], [1.0, b / a]))
+    # gates of folded qubits' leading runs disappear; everything else keeps its place
+    closed, body = set(), []
+    for op in ops:
+        one = _as_1q(op)
+        if one is not None and one[0] not in closed and one[0] in fold:
+            continue
+        closed.update(op.support())
+        body.append(op)
+    out = [ir.op_init(mask)] + front + body
+    if abs(gphase - 1.0) > 1e-15:
+        out.append(ir.op_diag([0], [gphase, gphase]))
+    return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -162,7 +211,7 @@ def _reduce_diag(qubits, table):
     return ir.op_diag(qubits, table)
 
 
-def fuse_monomial(ops, kmax=10):
+def fuse_monomial(ops, kmax=10, level_split=True):
     out = []
     pending = list(ops)
     pos = 0
@@ -199,6 +248,11 @@ def fuse_monomial(ops, kmax=10):
             win = None
             out.append(op)
             pos += 1
+            continue
+        if newq and win.ops and win.is_id and win.mark == len(win.ops) and len(win.ops) >= 1 and level_split:
+            # the run so far is a finished diagonal and the next gate reaches for a new qubit: emit
+            # it now, so diagonals do not straddle the blocks of a lowered circuit
+            flush()
             continue
         if len(win.q) + len(newq) > kmax:
             rem = flush()
@@ -332,14 +386,225 @@ def fuse_mux(ops, smax=8):
 
 
 # --------------------------------------------------------------------------------------------
-def optimise(ops, level=2, kmax=10, smax=8):
-    """level 0: gate by gate as ingested (|0..0> init prepended).
-    level 1: + init folding + diagonal (monomial) fusion.   level 2: + mux fusion."""
-    if level <= 0:
-        return [ir.op_init(0)] + list(ops)
-    ops = fold_init(ops)
+# pass 4: dense windows (<= 5 qubits) + structure recovery, for circuits lowered to a basis
+# --------------------------------------------------------------------------------------------
+_ZERO = 1e-13
+
+
+def _op_on_rows(U, op, pos):
+    """U <- G U for gate ``op`` acting on the row index of U; pos maps logical qubit -> row bit"""
+    rows = np.arange(U.shape[0])
+    k = op.kind
+    if k in ("u", "x"):
+        tb = pos[op.target]
+        fire = np.ones(rows.shape, dtype=bool)
+        for c, v in zip(op.ctrls, op.vals):
+            fire &= ((rows >> pos[c]) & 1) == v
+        r0 = rows[fire & (((rows >> tb) & 1) == 0)]
+        r1 = r0 | (1 << tb)
+        a, b = U[r0], U[r1]
+        if k == "x":
+            U[r0], U[r1] = b, a.copy()
+        else:
+            m = op.mat
+            U[r0], U[r1] = m[0, 0] * a + m[0, 1] * b, m[1, 0] * a + m[1, 1] * b
+    elif k == "mcphase":
+        fire = np.ones(rows.shape, dtype=bool)
+        for q, v in zip(op.qubits, op.vals):
+            fire &= ((rows >> pos[q]) & 1) == v
+        U[fire] *= np.exp(1j * op.angle)
+    elif k == "diag":
+        j = np.zeros_like(rows)
+        for e, q in enumerate(op.qubits):
+            j |= ((rows >> pos[q]) & 1) << e
+        U *= op.table[j][:, None]
+    elif k == "mux":
+        tb = pos[op.target]
+        r0 = rows[((rows >> tb) & 1) == 0]
+        r1 = r0 | (1 << tb)
+        j = np.zeros_like(r0)
+        for e, q in enumerate(op.ctrls):
+            j |= ((r0 >> pos[q]) & 1) << e
+        m = op.mats[j]
+        a, b = U[r0], U[r1]
+        U[r0] = m[:, 0, 0, None] * a + m[:, 0, 1, None] * b
+        U[r1] = m[:, 1, 0, None] * a + m[:, 1, 1, None] * b
+    else:                                                  # kq
+        kk = len(op.qubits)
+        offs = np.zeros(2 ** kk, dtype=np.int64)
+        qm = 0
+        for e, q in enumerate(op.qubits):
+            qm |= 1 << pos[q]
+            offs |= ((np.arange(2 ** kk) >> e) & 1) << pos[q]
+        base = rows[(rows & qm) == 0]
+        idx = base[None, :] | offs[:, None]
+        U[idx] = np.einsum("rc,cbn->rbn", op.mat, U[idx])
+    return U
+
+
+def _recover(qubits, U, n_ops):
+    """A dense window that is block diagonal in some of its qubits is really a diagonal / a
+    multiplexed 2x2: emit that (it rides in k_multi passes) instead of a dense gate."""
+    k = len(qubits)
+    idx = np.arange(2 ** k)
+    big = np.abs(U) > _ZERO
+    sel = []                                               # window bits in which U is block diagonal
+    for b in range(k):
+        rb = (idx >> b) & 1
+        if not big[rb[:, None] != rb[None, :]].any():
+            sel.append(b)
+    dense = [b for b in range(k) if b not in sel]
+    if not dense:
+        return [d for d in [_reduce_diag(qubits, np.diag(U).copy())] if d is not None]
+    if len(dense) == 1:
+        t = dense[0]
+        mats = np.zeros((2 ** len(sel), 2, 2), dtype=np.complex128)
+        for j in range(2 ** len(sel)):
+            r = 0
+            for e, b in enumerate(sel):
+                r |= ((j >> e) & 1) << b
+            for x in (0, 1):
+                for y in (0, 1):
+                    mats[j, x, y] = U[r | (x << t), r | (y << t)]
+        if not sel:
+            return [ir.op_u(qubits[t], mats[0], label="fused")]
+        # (diagonal on the selects) x (one 2x2 on t)?  then it is a plain gate plus a diagonal
+        m0 = mats[0]
+        r = np.einsum("xy,jxy->j", m0.conj(), mats) / np.vdot(m0, m0)
+        if np.abs(mats - r[:, None, None] * m0[None]).max() < _ZERO:
+            d = _reduce_diag([qubits[b] for b in sel], r)
+            return [ir.op_u(qubits[t], m0, label="fused")] + ([d] if d is not None else [])
+        return [ir.op_mux([qubits[b] for b in sel], qubits[t], mats)]
+    if n_ops < 3:
+        return None
+    return [ir.op_kq(qubits, U)]
+
+
+_OFFBLOCK = {}
+
+
+def _offblock_masks(k):
+    if k not in _OFFBLOCK:
+        idx = np.arange(2 ** k)
+        _OFFBLOCK[k] = [((idx >> b) & 1)[:, None] != ((idx >> b) & 1)[None, :] for b in range(k)]
+    return _OFFBLOCK[k]
+
+
+def _n_dense_bits(U):
+    """number of window bits in which U is NOT block diagonal"""
+    k = U.shape[0].bit_length() - 1
+    A = np.abs(U)
+    return sum(1 for m in _offblock_masks(k) if A[m].max() > _ZERO)
+
+
+class _DenseWindow:
+    def __init__(self):
+        self.q, self.pos, self.U, self.ops = [], {}, np.eye(1, dtype=np.complex128), []
+        self.mark = None                 # (n_ops, U copy, qubits) at the last structured point
+
+    def add(self, op):
+        for q in op.support():
+            if q not in self.pos:
+                self.pos[q] = len(self.q)
+                self.q.append(q)
+                n = self.U.shape[0]
+                grown = np.zeros((2 * n, 2 * n), dtype=np.complex128)
+                grown[:n, :n] = self.U
+                grown[n:, n:] = self.U
+                self.U = grown
+        _op_on_rows(self.U, op, self.pos)
+        self.ops.append(op)
+        # blocks of a lowered circuit end on a one-qubit gate: that is where the window may be
+        # exactly a diagonal / multiplexed 2x2 again -- remember the LATEST such point; when the
+        # window overflows it is cut there and the tail starts the next window
+        if len(op.support()) == 1 and len(self.ops) >= 2 and _n_dense_bits(self.U) <= 1:
+            self.mark = (len(self.ops), self.U.copy(), list(self.q))
+
+
+def fuse_dense(ops, kmax=5):
+    out = []
+    pending = list(ops)
+    pos = 0
+    win = None
+
+    def flush():
+        """emit the window (up to its last structured point, if it has one); return what is left"""
+        nonlocal win
+        if win is None or not win.ops:
+            win = None
+            return []
+        w, win = win, None
+        if w.mark is not None and w.mark[0] < len(w.ops):
+            n, U, q = w.mark
+            rec = _recover(q, U, n)
+            out.extend(rec if rec is not None else w.ops[:n])
+            return w.ops[n:]
+        rec = _recover(w.q, w.U, len(w.ops)) if len(w.ops) >= 2 else None
+        out.extend(rec if rec is not None else w.ops)
+        return []
+
+    while pos < len(pending):
+        op = pending[pos]
+        sup = op.support()
+        if op.kind not in ("u", "x", "diag", "mcphase", "mux", "kq") or len(set(sup)) > kmax:
+            rem = flush()
+            if rem:
+                pending[pos:pos] = rem
+                continue
+            out.append(op)
+            pos += 1
+            continue
+        if win is not None:
+            new = [q for q in sup if q not in win.pos]
+            if len(win.q) + len(new) > kmax:
+                rem = flush()
+                pending[pos:pos] = rem
+                continue
+        if win is None:
+            win = _DenseWindow()
+        win.add(op)
+        pos += 1
+    while True:
+        rem = flush()
+        if not rem:
+            break
+        win = _DenseWindow()
+        for op in rem:
+            win.add(op)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def _fuse_body(ops, level, kmax, smax, lowered=False):
     head, body = ops[:1], ops[1:]
+    if lowered and level >= 3:
+        # basis-gate input: re-assemble the blocks first, while the gate order is still pristine
+        body = fuse_dense(body)
     body = fuse_monomial(body, kmax=kmax)
     if level >= 2:
         body = fuse_mux(body, smax=smax)
+    if level >= 3 and not lowered:
+        body = fuse_dense(body)
     return head + body
+
+
+def optimise(ops, level=3, kmax=10, smax=8):
+    """level 0: gate by gate as ingested (|0..0> init prepended).
+    level 1: + init folding + diagonal (monomial) fusion.   level 2: + multiplexer fusion.
+    level 3: + dense <= 5-qubit windows with structure recovery (for basis-gate circuits)."""
+    if level <= 0:
+        return [ir.op_init(0)] + list(ops)
+    lead, rest = split_leading(ops)
+    cands = set(q for q, m in lead.items() if _is_hlike(m))
+    hold0 = set(q for op in rest for q in op.dense_targets()) & cands
+    if level < 3 or hold0 != cands or not cands:
+        return _fuse_body(fold_init(ops, hold=hold0), level, kmax, smax)
+    # every candidate looks dense in the raw stream: a circuit lowered to basis gates, where even
+    # pure select qubits are CX targets inside decompositions (and a CCX opens with rz-sx-rz on
+    # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the
+    # variable qubits' opening gates stand alone in front and are never dense again, so the
+    # ordinary rule applies to it.
+    fused = _fuse_body(fold_init(ops, hold=cands), level, kmax, smax, lowered=True)
+    refolded = fold_init(fused[1:])
+    refolded[0].mask |= fused[0].mask
+    return refolded

@@ -238,3 +238,31 @@ def test_zero_tracking_qcmrf_all_graphs(be, models):
     p = cf.probabilities(C, th)
     assert all(p[int(k, 2)] > 0 for k in counts)
     be.run(QCMRF(C, th), shots=0, engine_options={"zero_tracking": 0})
+
+
+@pytest.mark.parametrize("fusion", [0, 2, 3])
+def test_lowered_basis_gate_circuits(be, models, fusion):
+    """the form run_experiment.py:52-56 actually feeds the simulator: {cx, id, rz, sx, x}.
+    fusion 3 re-assembles the blocks (dense windows, f64 MFMA for what stays dense)."""
+    from qcmrf_amd import QCMRF
+    from qcmrf_amd.transpile import transpile
+    from test_host_logic import rand_circuit, oracle_state_of
+    for j in (1, 2, 4, 5):
+        C = models["0.25"]["GRAPHS"][j]
+        th = models["0.25"]["THETAS"][str(j)][2]
+        amp, meta = run_state(be, transpile(QCMRF(C, th)), fusion=fusion)
+        assert np.abs(amp - cf.amplitudes(C, th)).max() < 5e-12
+    for seed in (1, 2, 3):
+        qc = rand_circuit(11, 120, 70 + seed)
+        amp, meta = run_state(be, transpile(qc), fusion=fusion)
+        assert np.abs(amp - oracle_state_of(qc)).max() < 5e-12
+    C = gs.chain_cliques(8)                                   # W = 16: one mux per clique again
+    th = random_theta(28)
+    t = transpile(QCMRF(C, th))
+    amp, meta = run_state(be, t, fusion=fusion)
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 5e-12
+    if fusion == 3:
+        assert meta["n_device_ops"] < 20 < meta["n_source_ops"] / 100
+    counts = be.run(t, shots=3000, seed_simulator=5, fusion=fusion).result().get_counts()
+    p = cf.probabilities(C, th)
+    assert sum(counts.values()) == 3000 and all(p[int(k, 2)] > 1e-12 for k in counts)

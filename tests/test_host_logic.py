@@ -220,3 +220,74 @@ def test_open_controls_and_ctrl_state():
     sv.apply_1q(s, 0, sv.MATS["h"]); sv.apply_1q(s, 1, sv.MATS["h"])
     sv.apply_mcx(s, [0, 1], 2, [1, 0])
     assert np.abs(amp - s).max() < 1e-15
+
+
+# ---- circuits lowered to the reference's basis (run_experiment.py:52) ----------------------------
+def test_transpile_stand_in_is_exact_and_in_basis(models):
+    from qcmrf_amd.transpile import transpile, BASIS
+    for j in (0, 1, 2, 4, 6):
+        C = models["0.5"]["GRAPHS"][j]
+        th = models["0.5"]["THETAS"][str(j)][0]
+        t = transpile(QCMRF(C, th), basis_gates=['cx', 'id', 'rz', 'sx', 'x'])
+        assert set(ci.operation.name for ci in t.data) <= set(BASIS) | {"measure"}
+        for fusion in (0, 3):
+            amp, ing, pl, _ = run_numpy(t, fusion=fusion)
+            assert np.abs(amp - cf.amplitudes(C, th)).max() < 5e-12     # incl. the global phase
+        assert ing.measure == ingest(QCMRF(C, th)).measure
+    with pytest.raises(ValueError):
+        transpile(QCMRF([[0]], [-.1, -.2]), basis_gates=["u3", "cx"])
+
+
+def test_lowered_qcmrf_is_reassembled_into_one_multiplexer_per_clique():
+    """dense windows + structure recovery: ~390 basis gates per 2-clique collapse back to the
+    same init + one mux per clique the nested form gives (plus phase-only diagonals)"""
+    from qcmrf_amd.transpile import transpile
+    C = workloads.grid(2, 3)                                   # 7 cliques, W = 14
+    th = random_theta(cf.model_shape(C)[3])
+    t = transpile(QCMRF(C, th))
+    be = QsvBackend()
+    ing, pl = be.compile(t)
+    kinds = [o.kind for o in pl.ops]
+    assert len(t.data) > 2000 and kinds[0] == "init"
+    assert kinds.count("mux") == 7 and kinds.count("kq") == 0 and set(kinds) <= {"init", "mux", "diag"}
+    n = cf.model_shape(C)[0]
+    assert bin(be.compile(t, layout="reference")[1].ops[0].mask).count("1") == n     # variables folded into init
+    amp, _, _, _ = run_numpy(t)
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-11
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_lowered_circuits_dense_fusion(seed):
+    from qcmrf_amd.transpile import transpile
+    qc = rand_circuit(7, 70, 40 + seed)
+    t = transpile(qc)
+    want = oracle_state_of(qc)
+    for fusion in (0, 2, 3):
+        for shards in (1, 4):
+            amp, ing, pl, _ = run_numpy(t, fusion=fusion, shards=shards)
+            assert np.abs(amp - want).max() < 1e-11
+    assert len(pl.ops) < len(ing.ops) / 4
+
+
+def test_dense_window_recovery_kinds():
+    """_recover: block-diagonal windows come back as diag / u / mux, the rest as kq"""
+    rs = np.random.RandomState(0)
+    def ru(k):
+        q, _ = np.linalg.qr(rs.randn(2 ** k, 2 ** k) + 1j * rs.randn(2 ** k, 2 ** k))
+        return q
+    ops = [ir.op_kq([1, 4, 6], ru(3)), ir.op_u(4, ru(1)), ir.op_x(6, [1])]
+    out = passes.fuse_dense(ops)
+    assert [o.kind for o in out] == ["kq"] and set(out[0].qubits) == {1, 4, 6}
+    ops = [ir.op_u(2, ru(1), [5], [0]), ir.op_mcphase([5, 2], 0.3), ir.op_x(2, [5, 0])]
+    out = passes.fuse_dense(ops)
+    assert [o.kind for o in out] == ["mux"] and out[0].target == 2 and set(out[0].ctrls) == {5, 0}
+    ops = [ir.op_x(3, [1]), ir.op_mcphase([3, 1], 0.4), ir.op_x(3, [1])]
+    out = passes.fuse_dense(ops)
+    assert [o.kind for o in out] == ["diag"]
+    for o_in, o_out in ((ops, out),):
+        a = sv.zero_state(6); a[:] = rs.randn(64) + 1j * rs.randn(64)
+        b = a.copy()
+        e1, e2 = NumpyEngine(6), NumpyEngine(6)
+        e1.sh[0][:], e2.sh[0][:] = a, b
+        program.run_stepwise(e1, o_in); program.run_stepwise(e2, o_out)
+        assert np.abs(e1.sh[0] - e2.sh[0]).max() < 1e-14
