@@ -45,9 +45,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--qubits", type=int, default=0, help="override: grid MRF with this circuit width")
     ap.add_argument("--shots", type=int, default=4096)
-    ap.add_argument("--fusion", type=int, default=2)
+    ap.add_argument("--fusion", type=int, default=3)
     ap.add_argument("--layout", default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (untimed-for-value) legs")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--gates", action="store_true", help="gate-apply micro-benchmark (1 GPU)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
@@ -71,6 +72,7 @@ def cpu_baseline(cliques, theta, shots, budget_s):
     extrapolated to all m blocks (every block has the same gate mix).  Reported, not a target."""
     from oracle import cref, gate_stream as gs, closed_form as cf
     cref.build()
+    cref.set_threads(cref.host_threads())          # affinity / cgroup share, not the box's 256 logical CPUs
     n, m, W, dim = cf.model_shape(cliques)
     ops = gs.reference_stream(cliques, theta, with_measurements=False)
     # split into the H prologue and per-clique blocks (each starts with the H on its ancilla)
@@ -213,6 +215,31 @@ def main():
     counts = res.get_counts()
     assert sum(counts.values()) == args.shots
 
+    # untimed-for-`value` extra legs (every rank takes part; reported under "variants")
+    variants = {}
+
+    def leg(name, n, circuit=None, **opts):
+        comm.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = backend.run(circuit or qc, shots=args.shots, seed_simulator=77 + i, **opts).result()
+        backend.last_engine.sync()
+        comm.barrier()
+        dt = max(comm.allgather(time.perf_counter() - t0))
+        m = r.metadata(0)
+        variants[name] = {"shots_per_s": args.shots * n / dt, "ms_per_step": dt / n * 1e3,
+                          "device_ops": m["n_device_ops"], "evolve_ms": m["time_evolve"] * 1e3}
+
+    if not args.no_variants:
+        n = max(2, args.steps // 2)
+        leg("zero_tracking (opt-in: skips the provably-zero part of the vector)", n, engine_options={"zero_tracking": 1})
+        leg("unfused reference-order gate stream (fusion=0)", 1, fusion=0, engine_options={"zero_tracking": 0})
+        if world == 1:
+            from qcmrf_amd.transpile import transpile
+            leg("lowered to {cx,id,rz,sx,x} as run_experiment.py:52 (stand-in transpiler, not timed) -> fusion 3",
+                2, circuit=transpile(qc), fusion=args.fusion)
+        backend.run(qc, shots=16, engine_options={"zero_tracking": 0})
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         dom = max(agg, key=lambda k: agg[k]["ms"])
@@ -246,6 +273,7 @@ def main():
                          "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                          "avg_launch_ms": d["ms"] / d["launches"], "rank": 0},
         }
+        line["variants"] = variants
         if args.gpus == 1 and not args.no_cpu:
             backend.close()
             line["cpu_baseline"] = cpu_baseline(cliques, theta, args.shots, args.cpu_seconds)

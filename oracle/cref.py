@@ -40,6 +40,30 @@ def _dp(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def host_threads():
+    """threads this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def set_threads(n):
+    load().ref_set_threads(int(n))
+
+
 class RefState:
     """2^nq complex128 on the host, gates by OpenMP sweeps."""
 

@@ -36,6 +36,14 @@ static void sort_int(int* a, int n) {
   }
 }
 
+void ref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -1,7 +1,7 @@
 #!/bin/bash
 for zt in 0 1; do
   echo "== zero_tracking=$zt"
-  timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu --option zero_tracking=$zt | python -c "
+  timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu --no-variants --option zero_tracking=$zt | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 print('shots/s %.0f  ms/step %.2f  breakdown %s' % (d['value'], d['ms_per_step'], d['breakdown_ms']))
