@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--layout", default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (untimed-for-value) legs")
+    ap.add_argument("--with-exchange", action="store_true", help="N>1: also run the legs that need RCCL exchanges")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--gates", action="store_true", help="gate-apply micro-benchmark (1 GPU)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
@@ -181,7 +182,7 @@ def main():
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
-                         device=local_rank, devices=(0,))
+                         device=local_rank % max(1, _lib.device_count()), devices=(0,))
 
     def step(i, profile=False):
         res = backend.run(qc, shots=args.shots, seed_simulator=1984 + i, profile=profile).result()
@@ -233,7 +234,10 @@ def main():
     if not args.no_variants:
         n = max(2, args.steps // 2)
         leg("zero_tracking (opt-in: skips the provably-zero part of the vector)", n, engine_options={"zero_tracking": 1})
-        leg("unfused reference-order gate stream (fusion=0)", 1, fusion=0, engine_options={"zero_tracking": 0})
+        if world == 1 or args.with_exchange:
+            # N > 1: the unfused stream needs shard-bit exchanges (RCCL); opt-in there, because a
+            # first-ever RCCL bring-up must not be able to take the main measurement down with it
+            leg("unfused reference-order gate stream (fusion=0)", 1, fusion=0, engine_options={"zero_tracking": 0})
         if world == 1:
             from qcmrf_amd.transpile import transpile
             leg("lowered to {cx,id,rz,sx,x} as run_experiment.py:52 (stand-in transpiler, not timed) -> fusion 3",

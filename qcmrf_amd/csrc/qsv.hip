@@ -110,6 +110,12 @@ struct Shard {
   size_t xbuf_amps = 0;
   int n_cu = 256;
   uint64_t zmask = 0;            // zero tracking: local bits known |0>; memory with such a bit set is unwritten
+  std::vector<double> h_sums;    // host copy of the block sums, valid until the state changes
+  bool sums_valid = false;
+  uint64_t* d_sblk = nullptr;    // sampling scratch (block index, residual, result per shot)
+  double* d_sres = nullptr;
+  uint64_t* d_sout = nullptr;
+  size_t sample_cap = 0;
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
 };
@@ -199,6 +205,7 @@ static int launch(qsv_handle* h, Shard& s, int kind, double bytes, F&& f) {
   }
   f();
   HIPCHK(hipGetLastError());
+  if (kind != QSV_K_PROB) s.sums_valid = false;      // any state change drops the cached block sums
   if (h->profiling) {
     HIPCHK(hipEventRecord(p.e1, s.stream));
     s.pending.push_back(p);
@@ -273,6 +280,7 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.h_arena) hipHostFree(s.h_arena);
     if (s.d_sums) hipFree(s.d_sums);
     for (int b = 0; b < 2; ++b) if (s.xbuf[b]) hipFree(s.xbuf[b]);
+    if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
     if (s.stream) hipStreamDestroy(s.stream);
   }
   if (h->t0) hipEventDestroy(h->t0);
@@ -1008,6 +1016,7 @@ static int swap_local(qsv_handle* h, int a, int b) {
 
 // swap shard bit G (>= L) with local bit j
 static int exchange(qsv_handle* h, int G, int j) {
+  for (Shard& s : h->shards) s.sums_valid = false;
   const int gb = G - h->L;
   const uint64_t n = amps_local(h);
   const uint64_t nhalf = n >> 1;
@@ -1104,6 +1113,7 @@ extern "C" int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const in
 // measurement
 // ------------------------------------------------------------------------------------------
 static int block_sums(qsv_handle* h, Shard& s, std::vector<double>& sums) {
+  if (s.sums_valid) { sums = s.h_sums; return QSV_OK; }
   const uint64_t n = amps_local(h);
   const uint64_t nblk = (n + QSV_SBLOCK - 1) / QSV_SBLOCK;
   CHK(shard_set(s));
@@ -1111,9 +1121,11 @@ static int block_sums(qsv_handle* h, Shard& s, std::vector<double>& sums) {
     hipLaunchKernelGGL(k_blocksum, dim3((unsigned)std::min<uint64_t>(nblk, (uint64_t)s.n_cu * 16)), dim3(QSV_TPB), 0,
                        s.stream, s.amp, n, s.d_sums, nblk);
   }));
-  sums.resize(nblk);
-  HIPCHK(hipMemcpyAsync(sums.data(), s.d_sums, nblk * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+  s.h_sums.resize(nblk);
+  HIPCHK(hipMemcpyAsync(s.h_sums.data(), s.d_sums, nblk * sizeof(double), hipMemcpyDeviceToHost, s.stream));
   HIPCHK(hipStreamSynchronize(s.stream));
+  s.sums_valid = true;
+  sums = s.h_sums;
   return QSV_OK;
 }
 
@@ -1184,22 +1196,20 @@ extern "C" int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const in
         res[q] = std::max(0.0, x - pre);
       }
       CHK(shard_set(sh));
-      uint64_t* d_blk = nullptr;
-      double* d_res = nullptr;
-      uint64_t* d_out = nullptr;
-      HIPCHK(hipMalloc(&d_blk, cnt * sizeof(uint64_t)));
-      HIPCHK(hipMalloc(&d_res, cnt * sizeof(double)));
-      HIPCHK(hipMalloc(&d_out, cnt * sizeof(uint64_t)));
-      HIPCHK(hipMemcpyAsync(d_blk, blk.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, sh.stream));
-      HIPCHK(hipMemcpyAsync(d_res, res.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sh.stream));
+      if (sh.sample_cap < cnt) {
+        if (sh.d_sblk) { HIPCHK(hipFree(sh.d_sblk)); HIPCHK(hipFree(sh.d_sres)); HIPCHK(hipFree(sh.d_sout)); }
+        sh.sample_cap = std::max<size_t>(cnt, 8192);
+        HIPCHK(hipMalloc(&sh.d_sblk, sh.sample_cap * sizeof(uint64_t)));
+        HIPCHK(hipMalloc(&sh.d_sres, sh.sample_cap * sizeof(double)));
+        HIPCHK(hipMalloc(&sh.d_sout, sh.sample_cap * sizeof(uint64_t)));
+      }
+      HIPCHK(hipMemcpyAsync(sh.d_sblk, blk.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, sh.stream));
+      HIPCHK(hipMemcpyAsync(sh.d_sres, res.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sh.stream));
       hipLaunchKernelGGL(k_locate, dim3((unsigned)std::min<uint64_t>(cnt, 65535)), dim3(64), 0, sh.stream,
-                         sh.amp, amps_local(h), d_blk, d_res, d_out, cnt);
+                         sh.amp, amps_local(h), sh.d_sblk, sh.d_sres, sh.d_sout, cnt);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(&idx[s0], d_out, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, sh.stream));
+      HIPCHK(hipMemcpyAsync(&idx[s0], sh.d_sout, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, sh.stream));
       HIPCHK(hipStreamSynchronize(sh.stream));
-      HIPCHK(hipFree(d_blk));
-      HIPCHK(hipFree(d_res));
-      HIPCHK(hipFree(d_out));
       const uint64_t hi = (uint64_t)sh.index << h->L;
       for (uint64_t q = 0; q < cnt; ++q) idx[s0 + q] |= hi;
     }
@@ -1270,7 +1280,7 @@ static int amp_copy(qsv_handle* h, uint64_t start, uint64_t count, double* out, 
     CHK(shard_set(*sh));
     HIPCHK(hipStreamSynchronize(sh->stream));
     if (out) HIPCHK(hipMemcpy(out + 2 * done, sh->amp + off, m * sizeof(cplx), hipMemcpyDeviceToHost));
-    else     HIPCHK(hipMemcpy(sh->amp + off, in + 2 * done, m * sizeof(cplx), hipMemcpyHostToDevice));
+    else   { HIPCHK(hipMemcpy(sh->amp + off, in + 2 * done, m * sizeof(cplx), hipMemcpyHostToDevice)); sh->sums_valid = false; }
     done += m;
   }
   return QSV_OK;

@@ -364,15 +364,12 @@ def fuse_mux(ops, smax=8):
             win = _MuxWindow(op.target)
             # diagonals directly in front of the window that touch its target belong to it too
             back = []
+            sel = set(op.ctrls)
             while out and out[-1].kind in ("diag", "mcphase") and op.target in out[-1].qubits:
-                trial = _MuxWindow(op.target)
-                for o in [out[-1]] + back + [op]:
-                    if not trial.can_take(o, smax):
-                        trial = None
-                        break
-                    trial.take(o)
-                if trial is None:
+                more = sel | (set(out[-1].qubits) - {op.target})
+                if len(more) > smax:
                     break
+                sel = more
                 back.insert(0, out.pop())
             for o in back:
                 win.take(o)
