@@ -110,6 +110,17 @@ class QCMRF(QuantumCircuit):
             off += 2 ** len(C)
         return H
 
+    def sufficient_statistic_diagonal(self, C, y):
+        """Phi_{C,y} = prod_{v in C} |y_v><y_v| is a diagonal projector: returns its 0/1 diagonal
+        over the 2^n variable states (QCMRF.py:159-179 restated without opflow; same index
+        convention as ``hamiltonian_diagonal``)."""
+        n = self._n
+        idx = np.arange(2 ** n)
+        d = np.ones(2 ** n)
+        for v, b in zip(C, y):
+            d *= (((idx >> (n - 1 - v)) & 1) == int(bool(b)))
+        return d
+
     # ---- circuit construction (QCMRF.py:199-243) ---------------------------------------------
     def _clique_unitary(self, index, C, first_param):
         """cU_C: for every clique state y, AND . cp(2 gamma_y) . AND on (variables, scratch, ancilla)."""

@@ -266,3 +266,22 @@ def test_lowered_basis_gate_circuits(be, models, fusion):
     counts = be.run(t, shots=3000, seed_simulator=5, fusion=fusion).result().get_counts()
     p = cf.probabilities(C, th)
     assert sum(counts.values()) == 3000 and all(p[int(k, 2)] > 1e-12 for k in counts)
+
+
+def test_run_experiment_driver_end_to_end(tmp_path, models):
+    """python -m qcmrf_amd.run_experiment: same files as run_experiment.py:35-38,59-61, then
+    python -m qcmrf_amd.eval on its output (eval.py --mode file)."""
+    import json
+    from qcmrf_amd import run_experiment, eval as ev
+    counts = run_experiment.main(["--scale", "0.5", "--shots", "4000", "--outdir", str(tmp_path),
+                                  "--seed-simulator", "1984"])
+    m = json.load(open(tmp_path / "models_0.5.json"))
+    assert m["GRAPHS"] == models["0.5"]["GRAPHS"]
+    assert m["THETAS"] == models["0.5"]["THETAS"]                 # bit-identical theta draws
+    saved = json.load(open(tmp_path / "result_simulation_0.5.json"))
+    assert saved == counts and len(saved) == 70 and all(sum(c.values()) == 4000 for c in saved)
+    rows = ev.main(["--results", "result_simulation_0.5.json", "--scale", "0.5", "--resdir", str(tmp_path)])
+    assert all(r[1] > 0.99 for r in rows)                          # mean fidelity with the exact Gibbs pmf
+    deltas = [cf.success_probability(C, models["0.5"]["THETAS"][str(j)][0]) for j, C in enumerate(m["GRAPHS"])]
+    assert all(abs(r[4] - np.mean([cf.success_probability(C, th) for th in models["0.5"]["THETAS"][str(j)]])) < 0.02
+               for j, (C, r) in enumerate(zip(m["GRAPHS"], rows)))

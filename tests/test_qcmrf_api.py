@@ -107,3 +107,46 @@ def test_backend_surface_without_gpu():
     C = [[0, 1], [1, 2]]
     ing, pl = b.compile(QCMRF(C, [-0.2] * 8))
     assert [o.kind for o in pl.ops] == ["init", "mux", "mux"] and sorted(pl.layout) == list(range(6))
+
+
+def test_eval_module_reproduces_the_table_from_the_committed_aer_counts(tmp_path, aer_counts):
+    """qcmrf_amd.eval == eval.py --mode file arithmetic (tests/golden/eval_table.json)"""
+    from conftest import GOLDEN
+    from qcmrf_amd import eval as ev
+    table = json.load(open(GOLDEN + "/eval_table.json"))
+    for scale in ("0.1", "0.5"):
+        d = tmp_path / ("res_" + scale)
+        d.mkdir()
+        (d / "result_simulation.json").write_text(json.dumps(aer_counts[scale]))
+        rows = ev.main(["--results", "result_simulation.json", "--scale", scale, "--resdir", str(d)])
+        for row, want in zip(rows, table[scale]):
+            assert row[0] == want["graph"]
+            assert abs(row[1] - want["fidelity"]) < 1e-12 and abs(row[4] - want["delta_emp"]) < 1e-12
+    assert "fidelity" in ev.format_table(rows)
+    with pytest.raises(SystemExit):
+        ev.main(["--mode", "gibbs"])
+
+
+def test_mrf_module_matches_oracle(models):
+    from qcmrf_amd import mrf
+    for j, C in enumerate(models["0.25"]["GRAPHS"]):
+        th = models["0.25"]["THETAS"][str(j)][4]
+        p, lnZ = mrf.gibbs_pmf(C, th)
+        po, Z = cf.gibbs_pmf(C, th)
+        assert np.abs(p - po).max() < 1e-15 and abs(np.exp(lnZ) - Z) < 1e-12
+        assert abs(mrf.success_probability(C, th) - cf.success_probability(C, th)) < 1e-14
+        assert mrf.dimension(C) == cf.model_shape(C)[3]
+
+
+def test_sufficient_statistics_sum_to_hamiltonian():
+    import itertools
+    C = [[0, 2], [1, 2, 3]]
+    th = (-np.linspace(0.1, 1.2, 12)).tolist()
+    qc = QCMRF(C, th)
+    H = np.zeros(16)
+    i = 0
+    for Cl in C:
+        for y in itertools.product([0, 1], repeat=len(Cl)):
+            H += qc.sufficient_statistic_diagonal(Cl, y) * (-th[i])
+            i += 1
+    assert np.allclose(H, qc.hamiltonian_diagonal(), atol=1e-15)
