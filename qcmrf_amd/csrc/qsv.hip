@@ -112,6 +112,14 @@ struct Shard {
   uint64_t zmask = 0;            // zero tracking: local bits known |0>; memory with such a bit set is unwritten
   std::vector<double> h_sums;    // host copy of the block sums, valid until the state changes
   bool sums_valid = false;
+  // sums left behind by the last k_multi pass of a program, one per workgroup tile (no read pass)
+  double* d_tsums = nullptr;
+  size_t tsums_cap = 0;
+  bool tile_valid = false, tile_fresh = false;
+  int tile_R = 0;
+  RegPos tile_rp;
+  BitIns tile_ins;
+  uint64_t tile_nblocks = 0;
   uint64_t* d_sblk = nullptr;    // sampling scratch (block index, residual, result per shot)
   double* d_sres = nullptr;
   uint64_t* d_sout = nullptr;
@@ -136,6 +144,8 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = 0;
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
+  int opt_pair_variant = 0;           // experiments: see run_single
+  int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
@@ -205,7 +215,7 @@ static int launch(qsv_handle* h, Shard& s, int kind, double bytes, F&& f) {
   }
   f();
   HIPCHK(hipGetLastError());
-  if (kind != QSV_K_PROB) s.sums_valid = false;      // any state change drops the cached block sums
+  if (kind != QSV_K_PROB) { s.sums_valid = false; s.tile_valid = false; }   // any state change drops cached sums
   if (h->profiling) {
     HIPCHK(hipEventRecord(p.e1, s.stream));
     s.pending.push_back(p);
@@ -281,6 +291,7 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.d_sums) hipFree(s.d_sums);
     for (int b = 0; b < 2; ++b) if (s.xbuf[b]) hipFree(s.xbuf[b]);
     if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
+    if (s.d_tsums) hipFree(s.d_tsums);
     if (s.stream) hipStreamDestroy(s.stream);
   }
   if (h->t0) hipEventDestroy(h->t0);
@@ -572,6 +583,24 @@ static int run_single(qsv_handle* h, Shard& s, const LocalOp& lo) {
     uint64_t fixed = 0;
     for (int i = 0; i < nc; ++i) if (lo.cv[i]) fixed |= 1ull << lo.cq[i];
     const uint64_t tbit = 1ull << t;
+    if (h->opt_pair_variant && !lo.is_x && npairs % (QSV_TPB * 8 * 8) == 0) {
+      const int v = h->opt_pair_variant;
+      return launch(h, s, kind, bytes, [&] {
+#define PX(U, NL, NS, RM) hipLaunchKernelGGL((k_pair_x<U, NL, NS, RM>), dim3((unsigned)(npairs / (QSV_TPB * U))), dim3(QSV_TPB), 0, s.stream, s.amp, npairs, ins, fixed, tbit, mm)
+        switch (v) {
+          case 1: PX(4, false, false, false); break;   // baseline shape without the grid-stride loop
+          case 2: PX(4, false, true, false); break;    // nt stores only
+          case 3: PX(4, true, false, false); break;    // nt loads only
+          case 4: PX(4, false, false, true); break;    // XCD remap
+          case 5: PX(8, false, false, false); break;   // deeper unroll
+          case 6: PX(8, false, false, true); break;
+          case 7: PX(2, false, false, false); break;
+          case 8: PX(4, false, true, true); break;
+          default: PX(8, false, true, false); break;
+        }
+#undef PX
+      });
+    }
     return launch(h, s, kind, bytes, [&] {
       if (lo.is_x) { if (h->opt_nt) launch_pair<1, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<1, false>(h, s, npairs, ins, fixed, tbit, mm); }
       else         { if (h->opt_nt) launch_pair<0, true>(h, s, npairs, ins, fixed, tbit, mm); else launch_pair<0, false>(h, s, npairs, ins, fixed, tbit, mm); }
@@ -714,10 +743,10 @@ static void group_add(PendingGroup& g, LocalOp&& lo) {
 template <int R>
 static void launch_multi(const qsv_handle* h, const Shard& s, bool init, bool simple, uint64_t nthreads, const BitIns& ins,
                          const RegPos& rp, const MultiOp* dops, const MultiSlot* dslots, int nrounds,
-                         const cplx* dtab, int ntab, uint64_t nonmask, double initval, unsigned zreg) {
+                         const cplx* dtab, int ntab, uint64_t nonmask, double initval, unsigned zreg, double* tsums) {
   const dim3 g((unsigned)((nthreads + QSV_TPB - 1) / QSV_TPB));
   const size_t shm = (size_t)std::max(ntab, 1) * sizeof(cplx);
-#define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval, zreg)
+#define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval, zreg, tsums)
   if (init) { if (simple) QSV_LM(true, true); else QSV_LM(true, false); }
   else      { if (simple) QSV_LM(false, true); else QSV_LM(false, false); }
 #undef QSV_LM
@@ -736,7 +765,7 @@ static int materialize(qsv_handle* h, Shard& s) {
   });
 }
 
-static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
+static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass = false) {
   const uint64_t n = amps_local(h);
   CHK(shard_set(s));
   if (g.ops.empty()) {
@@ -879,20 +908,36 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g) {
   const bool init = g.init;
   const uint64_t nonmask = g.nonmask;
   const double initval = g.initval;
+  // the program's last pass also reduces |amp|^2 per workgroup tile: measurement then needs no read pass
+  double* tsums = nullptr;
+  if (final_pass && h->opt_fused_sums && nthreads % QSV_TPB == 0 && nthreads >= QSV_TPB) {
+    const uint64_t nb = nthreads / QSV_TPB;
+    if (s.tsums_cap < nb) {
+      if (s.d_tsums) HIPCHK(hipFree(s.d_tsums));
+      HIPCHK(hipMalloc(&s.d_tsums, nb * sizeof(double)));
+      s.tsums_cap = nb;
+    }
+    tsums = s.d_tsums;
+    s.tile_R = R;
+    s.tile_rp = rp;
+    s.tile_ins = ins;
+    s.tile_nblocks = nb;
+  }
   const int r = launch(h, s, QSV_K_MULTI, bytes, [&] {
     const MultiOp* o = reinterpret_cast<const MultiOp*>(dops);
     const MultiSlot* sl = reinterpret_cast<const MultiSlot*>(dslots);
     const cplx* tp = reinterpret_cast<const cplx*>(dtab);
     switch (R) {
-      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
-      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg); break;
+      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
     }
   });
+  s.tile_fresh = tsums != nullptr;
   g = PendingGroup();
   return r;
 }
@@ -1113,6 +1158,13 @@ extern "C" int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const in
 // measurement
 // ------------------------------------------------------------------------------------------
 static int block_sums(qsv_handle* h, Shard& s, std::vector<double>& sums) {
+  if (s.tile_valid) {                        // left behind by the last k_multi pass: no read pass
+    CHK(shard_set(s));
+    sums.resize(s.tile_nblocks);
+    HIPCHK(hipMemcpyAsync(sums.data(), s.d_tsums, s.tile_nblocks * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    return QSV_OK;
+  }
   if (s.sums_valid) { sums = s.h_sums; return QSV_OK; }
   const uint64_t n = amps_local(h);
   const uint64_t nblk = (n + QSV_SBLOCK - 1) / QSV_SBLOCK;
@@ -1205,8 +1257,18 @@ extern "C" int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const in
       }
       HIPCHK(hipMemcpyAsync(sh.d_sblk, blk.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, sh.stream));
       HIPCHK(hipMemcpyAsync(sh.d_sres, res.data(), cnt * sizeof(double), hipMemcpyHostToDevice, sh.stream));
-      hipLaunchKernelGGL(k_locate, dim3((unsigned)std::min<uint64_t>(cnt, 65535)), dim3(64), 0, sh.stream,
-                         sh.amp, amps_local(h), sh.d_sblk, sh.d_sres, sh.d_sout, cnt);
+      if (sh.tile_valid) {
+        const dim3 g((unsigned)std::min<uint64_t>(cnt, 65535));
+#define LT(RR) hipLaunchKernelGGL((k_locate_tile<RR>), g, dim3(QSV_TPB), 0, sh.stream, sh.amp, sh.tile_ins, sh.tile_rp, sh.d_sblk, sh.d_sres, sh.d_sout, cnt)
+        switch (sh.tile_R) {
+          case 0: LT(0); break; case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break;
+          case 4: LT(4); break; case 5: LT(5); break; default: LT(6); break;
+        }
+#undef LT
+      } else {
+        hipLaunchKernelGGL(k_locate, dim3((unsigned)std::min<uint64_t>(cnt, 65535)), dim3(64), 0, sh.stream,
+                           sh.amp, amps_local(h), sh.d_sblk, sh.d_sres, sh.d_sout, cnt);
+      }
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(&idx[s0], sh.d_sout, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, sh.stream));
       HIPCHK(hipStreamSynchronize(sh.stream));
@@ -1295,10 +1357,11 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
   if (!h || (n_ops && !ops)) return fail(QSV_E_BADARG, "NULL argument");
   const size_t ns = h->shards.size();
   std::vector<PendingGroup> pend(ns);
-  auto flush_all = [&]() -> int {
-    for (size_t i = 0; i < ns; ++i) CHK(flush_group(h, h->shards[i], pend[i]));
+  auto flush_all = [&](bool final_pass = false) -> int {
+    for (size_t i = 0; i < ns; ++i) CHK(flush_group(h, h->shards[i], pend[i], final_pass));
     return QSV_OK;
   };
+  for (Shard& s : h->shards) s.tile_fresh = false;
   for (int i = 0; i < n_ops; ++i) {
     const qsv_op& o = ops[i];
     if (o.n < 0 || o.n > QSV_MAX_CTRL) return fail(QSV_E_BADARG, "op %d: n=%d out of range", i, o.n);
@@ -1361,8 +1424,12 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
         return fail(QSV_E_BADARG, "op %d: unknown kind %d", i, o.kind);
     }
   }
-  CHK(flush_all());
-  for (Shard& s : h->shards) CHK(materialize(h, s));
+  CHK(flush_all(true));
+  for (Shard& s : h->shards) {
+    CHK(materialize(h, s));                  // writes zeros only: the tile sums stay right
+    s.tile_valid = s.tile_fresh;
+    s.tile_fresh = false;
+  }
   return QSV_OK;
 }
 
@@ -1413,6 +1480,8 @@ extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "unroll")) h->opt_unroll = value;
   else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
   else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "fused_sums")) h->opt_fused_sums = value != 0;
+  else if (!strcmp(name, "pair_variant")) h->opt_pair_variant = value;
   else if (!strcmp(name, "kq_mfma")) h->opt_kq_mfma = value != 0;
   else if (!strcmp(name, "zero_tracking")) h->opt_zero_tracking = value != 0;
   else if (!strcmp(name, "multi_r")) { if (value < 0 || value > QSV_MULTI_MAXR) return fail(QSV_E_BADARG, "multi_r out of range"); h->opt_multi_r = value; }

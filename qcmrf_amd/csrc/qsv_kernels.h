@@ -433,6 +433,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
 // and diagonal selects may sit on any bit (register, lane or block bits).
 // HBM traffic: one read + one write of the shard (32 B / amplitude) for up to ~a dozen gates.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v);
 #define QSV_MULTI_MAXR 6
 #define QSV_MULTI_MAXLIST 10
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
                                                    const MultiSlot* __restrict__ slots, int nrounds,
                                                    const cplx* __restrict__ tables, int ntab,
                                                    uint64_t nonmask, double initval,
-                                                   unsigned int zreg) {
+                                                   unsigned int zreg, double* __restrict__ tile_sums) {
   // zreg (zero tracking): register bits whose qubit is still known to be |0> on entry -- every
   // amplitude with such a bit set is zero by construction and is not read (memory there may be
   // unwritten).  `ins` then also holds the known-zero NON-register bits, so only the populated
@@ -596,12 +597,24 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
     if constexpr (R > 4) multi_slot<R, 4, SIMPLE>(a, ops, rs, base, lt);
     if constexpr (R > 5) multi_slot<R, 5, SIMPLE>(a, ops, rs, base, lt);
   }
+  double psum = 0.0;
 #pragma unroll
   for (int j = 0; j < (1 << R); ++j) {
     uint64_t off = 0;
 #pragma unroll
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
     (pblk + off)[base_thr] = a[j];
+    psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
+  }
+  // last pass of a program: leave sum |amp|^2 of this workgroup's tile behind, so that measurement
+  // needs no separate read pass over the shard (workgroups are full: nthreads % 256 == 0 is
+  // checked on the host before tile_sums is passed)
+  if (tile_sums) {
+    __shared__ double wpart[QSV_TPB / 64];
+    psum = wave_sum(psum);
+    if ((threadIdx.x & 63) == 0) wpart[threadIdx.x >> 6] = psum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
   }
 }
 
@@ -675,5 +688,107 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
         double* p = reinterpret_cast<double*>(amp + (base | offs.off[mb * 16 + kq + 4 * r])) + part;
         *p = acc[mb][r];
       }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// tuning variant of the dense pair kernel (selected by option "pair_variant"): separate
+// non-temporal hints for loads / stores, deeper unroll, and an XCD-aware block remap (blocks are
+// dealt round-robin over the 8 XCDs; the remap gives every XCD one contiguous eighth of the pairs)
+// ---------------------------------------------------------------------------------------
+template <int U, bool NTL, bool NTS, bool REMAP>
+__global__ __launch_bounds__(QSV_TPB) void k_pair_x(cplx* __restrict__ amp, uint64_t npairs,
+                                                    BitIns ins, uint64_t fixed, uint64_t tbit, Mat2 m) {
+  const cplx m00 = make_double2(m.v[0], m.v[1]), m01 = make_double2(m.v[2], m.v[3]);
+  const cplx m10 = make_double2(m.v[4], m.v[5]), m11 = make_double2(m.v[6], m.v[7]);
+  uint64_t blk = blockIdx.x;
+  if (REMAP) {
+    const uint64_t nb = gridDim.x, q = nb >> 3;            // nb is a multiple of 8 (checked on the host)
+    blk = (blk & 7) * q + (blk >> 3);
+  }
+  const uint64_t base = blk * (QSV_TPB * U) + threadIdx.x;
+  uint64_t i0[U];
+  cplx a0[U], a1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = ins_bits(base + (uint64_t)u * QSV_TPB, ins) | fixed;
+    a0[u] = NTL ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
+    a1[u] = NTL ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const cplx r0 = cmad(m01, a1[u], cmul(m00, a0[u]));
+    const cplx r1 = cmad(m11, a1[u], cmul(m10, a0[u]));
+    if (NTS) { st_nt(amp + i0[u], r0); st_nt(amp + (i0[u] | tbit), r1); }
+    else     { st(amp + i0[u], r0);    st(amp + (i0[u] | tbit), r1); }
+  }
+}
+
+// one workgroup per shot, tiles in the order the last k_multi pass left them: thread t owns the
+// 2^R amplitudes base(t) | off(j); find the first (t, j) whose running |amp|^2 exceeds resid[s]
+template <int R>
+__global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict__ amp, BitIns ins, RegPos rp,
+                                                         const uint64_t* __restrict__ blk,
+                                                         const double* __restrict__ resid,
+                                                         uint64_t* __restrict__ out, uint64_t shots) {
+  __shared__ double wtot[QSV_TPB / 64];
+  __shared__ unsigned long long found;
+  __shared__ unsigned long long lastnz;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t s = blockIdx.x; s < shots; s += gridDim.x) {
+    const uint64_t base = ins_bits(blk[s] * QSV_TPB + threadIdx.x, ins);
+    const double r = resid[s];
+    double p[1 << R];
+    double mine = 0.0;
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      uint64_t off = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
+      const cplx a = amp[base | off];
+      p[j] = fma(a.x, a.x, a.y * a.y);
+      mine += p[j];
+    }
+    double inc = mine;                                  // inclusive scan over the 256 threads
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (threadIdx.x == 0) { found = ~0ull; lastnz = ~0ull; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    double before = 0.0;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    const double hi = before + inc, lo = hi - mine;
+    // the owner of the crossing scans its registers; the last populated thread records a fallback
+    if (mine > 0.0) atomicMax(&lastnz, (unsigned long long)threadIdx.x);
+    if (mine > 0.0 && lo <= r && r < hi) {
+      double run = lo;
+      int jhit = -1, jlast = 0;
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        if (p[j] > 0.0) { jlast = j; run += p[j]; if (jhit < 0 && run > r) jhit = j; }
+      }
+      if (jhit < 0) jhit = jlast;
+      uint64_t off = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((jhit >> c) & 1) off |= 1ull << rp.pos[c];
+      atomicMin(&found, (unsigned long long)(base | off));
+    }
+    __syncthreads();
+    if (found == ~0ull && lastnz != ~0ull && threadIdx.x == (unsigned)lastnz) {
+      // rounding slack ran past the tile: take the last populated amplitude of the last populated thread
+      int jlast = 0;
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) if (p[j] > 0.0) jlast = j;
+      uint64_t off = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((jlast >> c) & 1) off |= 1ull << rp.pos[c];
+      found = base | off;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] = found;
+    __syncthreads();
   }
 }

@@ -273,15 +273,44 @@ def test_run_experiment_driver_end_to_end(tmp_path, models):
     python -m qcmrf_amd.eval on its output (eval.py --mode file)."""
     import json
     from qcmrf_amd import run_experiment, eval as ev
-    counts = run_experiment.main(["--scale", "0.5", "--shots", "4000", "--outdir", str(tmp_path),
+    counts = run_experiment.main(["--scale", "0.5", "--shots", "10000", "--outdir", str(tmp_path),
                                   "--seed-simulator", "1984"])
     m = json.load(open(tmp_path / "models_0.5.json"))
     assert m["GRAPHS"] == models["0.5"]["GRAPHS"]
     assert m["THETAS"] == models["0.5"]["THETAS"]                 # bit-identical theta draws
     saved = json.load(open(tmp_path / "result_simulation_0.5.json"))
-    assert saved == counts and len(saved) == 70 and all(sum(c.values()) == 4000 for c in saved)
+    assert saved == counts and len(saved) == 70 and all(sum(c.values()) == 10000 for c in saved)
     rows = ev.main(["--results", "result_simulation_0.5.json", "--scale", "0.5", "--resdir", str(tmp_path)])
     assert all(r[1] > 0.99 for r in rows)                          # mean fidelity with the exact Gibbs pmf
     deltas = [cf.success_probability(C, models["0.5"]["THETAS"][str(j)][0]) for j, C in enumerate(m["GRAPHS"])]
     assert all(abs(r[4] - np.mean([cf.success_probability(C, th) for th in models["0.5"]["THETAS"][str(j)]])) < 0.02
                for j, (C, r) in enumerate(zip(m["GRAPHS"], rows)))
+
+
+@pytest.mark.parametrize("zero_tracking", [0, 1])
+@pytest.mark.parametrize("multi_r", [2, 5, 6])
+def test_fused_tile_sums_sampling(be, multi_r, zero_tracking):
+    """the last k_multi pass leaves per-tile |amp|^2 sums; sampling from them (tile-order locate
+    kernel) must follow the same distribution as the separate read pass, reproducibly"""
+    from qcmrf_amd import QCMRF
+    C = gs.chain_cliques(9)                                    # W = 18
+    th = random_theta(32)
+    qc = QCMRF(C, th)
+    p = cf.probabilities(C, th)
+    shots = 60000
+    res = {}
+    for fused in (1, 0):
+        opts = {"multi_r": multi_r, "zero_tracking": zero_tracking, "fused_sums": fused}
+        c1 = be.run(qc, shots=shots, seed_simulator=42, engine_options=opts).result().get_counts()
+        c2 = be.run(qc, shots=shots, seed_simulator=42, engine_options=opts).result().get_counts()
+        assert c1 == c2
+        assert abs(be.last_engine.norm() - 1.0) < 1e-12
+        obs = np.zeros(p.size)
+        for k, v in c1.items():
+            obs[int(k, 2)] += v
+        assert obs[p == 0].sum() == 0
+        sel = p * shots > 5
+        chi = ((obs[sel] - p[sel] * shots) ** 2 / (p[sel] * shots)).sum() / (sel.sum() - 1)
+        assert 0.85 < chi < 1.15, (fused, chi)
+        res[fused] = obs
+    be.run(qc, shots=0, engine_options={"multi_r": 5, "zero_tracking": 0, "fused_sums": 1})
