@@ -148,22 +148,19 @@ def test_extract_probs_pipeline(be, models):
     assert abs(delta - Z / 2 ** qc.num_vertices) < 0.01
 
 
-def test_full_size_w28_properties(be):
-    """BASELINE config 3 (2x6 grid minus last edge, W = 28, 4 GiB state): size-independent checks.
-    norm = 1; P(all ancillas 0) = Z/2^n; P(x | ancillas 0) = Gibbs pmf (1e-10); random amplitude
-    slices equal the closed form (1e-12)."""
+def _full_size_properties(be, C, **opts):
+    """size-independent checks at sizes no oracle can hold: norm = 1; P(all ancillas 0) = Z/2^n;
+    P(x | ancillas 0) = Gibbs pmf (1e-10); random amplitude slices (incl. the very top of the
+    index range: 64-bit addressing) equal the closed form (1e-12); counts only on the support."""
     from qcmrf_amd import QCMRF
-    C = gs.grid_cliques(2, 6, drop_last=1)
     n, m, W, dim = cf.model_shape(C)
-    assert (n, m, W, dim) == (12, 15, 28, 60)
     th = random_theta(dim)
     qc = QCMRF(C, th)
-    res = be.run(qc, shots=4096, seed_simulator=1984).result()
+    res = be.run(qc, shots=4096, seed_simulator=1984, **opts).result()
     meta = res.metadata(0)
     lay = meta["layout"]
     eng = be.last_engine
     assert abs(eng.norm() - 1.0) < 1e-12
-    # conditional distribution over the variable qubits given every other qubit reads 0
     var_phys = [lay[q] for q in range(n)]
     fix_mask = 0
     for q in range(n, W):
@@ -172,23 +169,46 @@ def test_full_size_w28_properties(be):
     p, Z = cf.gibbs_pmf(C, th)                              # index has x_0 as MSB; variable v on qubit n-1-v
     assert abs(px.sum() - Z / 2 ** n) < 1e-10
     assert np.abs(px / px.sum() - p).max() < 1e-10
-    # amplitude slices
     rs = np.random.RandomState(0)
-    linv = logical_index(lay, W) if W <= 20 else None
-    for start in rs.randint(0, 2 ** W - 4096, size=16).tolist() + [0, 2 ** W - 4096]:
+    starts = [int(x) for x in rs.randint(0, 2 ** 31 - 1, size=12).astype(np.int64) * (2 ** W // 2 ** 31)] + [0, 2 ** W - 4096]
+    for start in starts:
+        start = min(max(start, 0), 2 ** W - 4096)
         got = eng.amplitudes(start, 4096)
         pidx = np.arange(start, start + 4096, dtype=np.uint64)
         lidx = np.zeros_like(pidx)
         for q, pos in enumerate(lay):
             lidx |= ((pidx >> np.uint64(pos)) & np.uint64(1)) << np.uint64(q)
         assert np.abs(got - cf.amplitudes_at(C, th, lidx)).max() < 1e-12
-    # counts: only supported keys, success rate within sampling error
     counts = res.get_counts()
     assert sum(counts.values()) == 4096
     ok = sum(v for k, v in counts.items() if int(k, 2) < 2 ** n)
     delta = Z / 2 ** n
     assert abs(ok / 4096 - delta) < 5 * np.sqrt(delta * (1 - delta) / 4096) + 1e-3
     assert all(k[W - 1 - n] == "0" for k in counts)         # classical bit n is never written
+    pr = cf.probabilities_at(C, th, np.array([int(k, 2) for k in counts], dtype=np.uint64))
+    assert (pr > 0).all()
+    return meta
+
+
+def test_full_size_w28_properties(be):
+    """BASELINE config 3 (2x6 grid minus last edge, W = 28, 4 GiB state)"""
+    C = gs.grid_cliques(2, 6, drop_last=1)
+    assert cf.model_shape(C) == (12, 15, 28, 60)
+    meta = _full_size_properties(be, C)
+    assert meta["n_device_ops"] == 16
+    _full_size_properties(be, C, engine_options={"zero_tracking": 1})
+    _full_size_properties(be, C, fusion=1, engine_options={"zero_tracking": 0})
+
+
+def test_full_size_w32_64bit_addressing(be):
+    """a 64 GiB shard (the size class of the 8-GPU config's 32 GiB shards and beyond): every byte
+    offset above 2^32 and every index above 2^31 is live here"""
+    from qcmrf_amd import workloads
+    C = workloads.for_width(32)
+    assert cf.model_shape(C)[2] == 32
+    _full_size_properties(be, C)
+    _full_size_properties(be, C, engine_options={"zero_tracking": 1})
+    be.run(__import__("qcmrf_amd").QCMRF([[0, 1]], [-0.1] * 4), shots=1, engine_options={"zero_tracking": 0})   # frees the 64 GiB
 
 
 @pytest.mark.parametrize("zero_tracking", [0, 1])
