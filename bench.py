@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (untimed-for-value) legs")
     ap.add_argument("--with-exchange", action="store_true", help="N>1: also run the legs that need RCCL exchanges")
+    ap.add_argument("--virtual-shards", type=int, default=0,
+                    help="1 GPU: split the vector into this many shards on device 0 (config-4 rehearsal: real "
+                         "shard-bit resolution and exchange kernels, device copies instead of xGMI)")
+    ap.add_argument("--config", type=int, default=0, help="force BASELINE configs[i] (1..4) regardless of --gpus")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--gates", action="store_true", help="gate-apply micro-benchmark (1 GPU)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
@@ -62,7 +66,7 @@ def workload(args):
         C = wl.for_width(args.qubits)
         name = "grid MRF, W=%d (n=%d, m=%d)" % (args.qubits, wl.width(C) - len(C) - 1, len(C))
     else:
-        name, C = wl.baseline_config({1: 2, 2: 3, 4: 3, 8: 4}.get(args.gpus, 2))
+        name, C = wl.baseline_config(args.config or {1: 2, 2: 3, 4: 3, 8: 4}.get(args.gpus, 2))
     return name, C, wl.theta_halfnorm(wl.dimension(C))
 
 
@@ -182,7 +186,8 @@ def main():
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
-                         device=local_rank % max(1, _lib.device_count()), devices=(0,))
+                         device=local_rank % max(1, _lib.device_count()),
+                         devices=(0,) * max(1, args.virtual_shards))
 
     def step(i, profile=False):
         res = backend.run(qc, shots=args.shots, seed_simulator=1984 + i, profile=profile).result()
@@ -266,7 +271,8 @@ def main():
                        "layout": args.layout, "state_GiB": 16.0 * 2 ** W / 2 ** 30,
                        "sweeps_per_step": sum(a["launches"] for k, a in agg.items() if k != "prob") // args.steps,
                        "source_gates": meta["n_source_ops"], "exchanges_per_step": meta["n_exchanges"],
-                       "parallelism": "amplitude shards by high qubit x%d" % args.gpus},
+                       "parallelism": "amplitude shards by high qubit x%d" % (args.virtual_shards or args.gpus)
+                                      + (" (virtual shards on one device)" if args.virtual_shards else "")},
             "breakdown_ms": {"compile": t_compile / args.steps * 1e3, "evolve": t_evolve / args.steps * 1e3,
                              "sample": t_sample / args.steps * 1e3},
             "kernels": {k: {"launches_per_step": a["launches"] / args.steps,

@@ -157,6 +157,10 @@ int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const int* meas_qub
 int qsv_get_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, double* out);
 int qsv_set_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, const double* in);
 
+/* dst <- src (same n_qubits and shard structure), device to device.  Branch points of the
+ * trajectory mode: the mid-circuit measure of QCMRF.py:238-239 taken when it occurs. */
+int qsv_copy_state(qsv_handle* dst, qsv_handle* src);
+
 /* ---- batched execution -------------------------------------------------------------- */
 
 enum {

@@ -201,6 +201,21 @@ class NumpyEngine:
             elif kind == "swap":
                 self.swap_layout(q, v)
 
+    def probabilities(self, qubits, fix_mask=0, fix_val=0):
+        out = np.zeros(2 ** len(qubits))
+        for s in self.owned:
+            g = (s << self.L) | np.arange(2 ** self.L)
+            sel = (g & fix_mask) == fix_val
+            j = np.zeros_like(g)
+            for b, q in enumerate(qubits):
+                j |= ((g >> q) & 1) << b
+            out += np.bincount(j[sel], weights=np.abs(self.sh[s][sel]) ** 2, minlength=out.size)
+        return out
+
+    def copy_from(self, other):
+        for s in self.owned:
+            self.sh[s][:] = other.sh[s]
+
     def sync(self): pass
     def close(self): pass
     def reset_stats(self): pass

@@ -73,6 +73,7 @@ SIGNATURES = {
     "qsv_sample": (_i, [_vp, _u64, _u64, _ip, _i, _u64p]),
     "qsv_get_amplitudes": (_i, [_vp, _u64, _u64, _dp]),
     "qsv_set_amplitudes": (_i, [_vp, _u64, _u64, _dp]),
+    "qsv_copy_state": (_i, [_vp, _vp]),
     "qsv_exec": (_i, [_vp, _vp, _i, _dp, _u64]),
     "qsv_set_profiling": (_i, [_vp, _i]),
     "qsv_reset_stats": (_i, [_vp]),
@@ -292,6 +293,10 @@ class Engine:
         out = np.empty(int(count), dtype=np.complex128)
         _chk(self._lib.qsv_get_amplitudes(self._h, int(start), int(count), out.view(np.float64).ctypes.data_as(_dp)))
         return out
+
+    def copy_from(self, other):
+        """device-to-device copy of another engine's state (same shape)"""
+        _chk(self._lib.qsv_copy_state(self._h, other._h))
 
     def set_amplitudes(self, start, values):
         v = np.ascontiguousarray(values, dtype=np.complex128)

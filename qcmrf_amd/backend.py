@@ -93,6 +93,9 @@ class QsvBackend:
                 3 + dense <=5-qubit windows with structure recovery (default)
     layout      'auto' (exchange-free where possible) | 'reference' (qubit q on index bit q)
     devices     HIP device id per shard owned by this process (repeat an id for virtual shards)
+    method      'statevector' (default: all measurements deferred, one evolution, W qubits) |
+                'trajectory' (mid-circuit measurements taken when they occur, measured qubits
+                released: n+2 live qubits for a QCMRF circuit, see qcmrf_amd.trajectory)
     comm        process group for one-process-per-GPU launches (qcmrf_amd.comm)
     device      HIP device of this rank when ``comm`` is given
     """
@@ -100,7 +103,7 @@ class QsvBackend:
     def __init__(self, name="qasm_simulator", **options):
         self._name = name
         self.options = {"fusion": 3, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
-                        "profile": False, "engine_options": None}
+                        "profile": False, "engine_options": None, "method": "statevector"}
         self.options.update(options)
         self._engine = None
         self._engine_key = None
@@ -180,7 +183,25 @@ class QsvBackend:
         pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"])
         return ing, pl
 
+    def _run_trajectory(self, circuit, shots, seed, opts):
+        from . import trajectory
+        t0 = time.perf_counter()
+        vals, cnts, num_clbits, creg_sizes, meta = trajectory.run_trajectories(
+            circuit, shots, seed, fusion=opts["fusion"], device=tuple(opts["devices"])[0],
+            engine_factory=self._engine_factory)
+        agg = {}
+        for v, c in zip(vals.tolist(), cnts.tolist()):
+            agg[v] = agg.get(v, 0) + c
+        uv = np.fromiter(agg.keys(), dtype=np.uint64, count=len(agg))
+        uc = np.fromiter(agg.values(), dtype=np.int64, count=len(agg))
+        counts = _format_keys(uv, uc, num_clbits, creg_sizes) if len(agg) else {}
+        meta.update({"n_qubits": int(circuit.num_qubits), "time_taken": time.perf_counter() - t0,
+                     "time_sample": 0.0, "seed_simulator": seed, "fusion": opts["fusion"]})
+        return {"name": getattr(circuit, "name", "circuit"), "shots": shots, "counts": counts, "metadata": meta}
+
     def _run_one(self, circuit, shots, seed, opts):
+        if opts.get("method", "statevector") == "trajectory":
+            return self._run_trajectory(circuit, shots, seed, opts)
         comm = opts["comm"] or SingleProcess()
         t0 = time.perf_counter()
         n_shards = comm.world if comm.world > 1 else len(opts["devices"])

@@ -1347,6 +1347,27 @@ static int amp_copy(qsv_handle* h, uint64_t start, uint64_t count, double* out, 
   }
   return QSV_OK;
 }
+extern "C" int qsv_copy_state(qsv_handle* dst, qsv_handle* src) {
+  if (!dst || !src) return fail(QSV_E_BADARG, "NULL handle");
+  if (dst->W != src->W || dst->P != src->P || dst->shards.size() != src->shards.size())
+    return fail(QSV_E_BADARG, "qsv_copy_state: handles differ in shape (%d/%d qubits, %d/%d shards)", dst->W, src->W, dst->P, src->P);
+  const size_t bytes = amps_local(src) * sizeof(cplx);
+  for (size_t i = 0; i < src->shards.size(); ++i) {
+    Shard& a = src->shards[i];
+    Shard& b = dst->shards[i];
+    if (a.index != b.index) return fail(QSV_E_BADARG, "qsv_copy_state: shard order differs");
+    CHK(shard_set(a));
+    HIPCHK(hipStreamSynchronize(a.stream));
+    CHK(shard_set(b));
+    HIPCHK(hipMemcpyAsync(b.amp, a.amp, bytes, hipMemcpyDeviceToDevice, b.stream));
+    b.zmask = a.zmask;
+    b.sums_valid = false;
+    b.tile_valid = false;
+    dst->stats.per_kind[QSV_K_SWAP].launches += 1;
+    dst->stats.per_kind[QSV_K_SWAP].algorithmic_bytes += 2.0 * (double)bytes;
+  }
+  return QSV_OK;
+}
 extern "C" int qsv_get_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, double* out) { return amp_copy(h, start, count, out, nullptr); }
 extern "C" int qsv_set_amplitudes(qsv_handle* h, uint64_t start, uint64_t count, const double* in) { return amp_copy(h, start, count, nullptr, in); }
 

@@ -204,6 +204,8 @@ def _walk(circuit, qmap, cmap, out, depth):
             out.measure[c[0]] = q[0]
             out._measured.add(q[0])
             out.n_source_ops += 1
+            if out.keep_measures:                       # trajectory mode needs WHEN it happens
+                out.ops.append(ir.Op("measure", target=q[0], mask=c[0]))
             continue
         if name in ("barrier", "delay"):
             continue
@@ -237,13 +239,14 @@ def _walk(circuit, qmap, cmap, out, depth):
                          "carries no definition" % (name, len(q)))
 
 
-def ingest(circuit, peephole=False):
+def ingest(circuit, peephole=False, keep_measures=False):
     """peephole=True additionally folds X..X . MCX . X..X definitions (Qiskit's AND with negative
     flags) into one MCX with negated controls while walking -- exact, and 5x fewer ops to fuse."""
     nq = int(circuit.num_qubits)
     nc = int(getattr(circuit, "num_clbits", 0))
     out = Ingested(nq, nc)
     out.peephole = bool(peephole)
+    out.keep_measures = bool(keep_measures)
     out._measured = set()
     _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
     cregs = getattr(circuit, "cregs", None)

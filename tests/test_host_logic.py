@@ -291,3 +291,55 @@ def test_dense_window_recovery_kinds():
         e1.sh[0][:], e2.sh[0][:] = a, b
         program.run_stepwise(e1, o_in); program.run_stepwise(e2, o_out)
         assert np.abs(e1.sh[0] - e2.sh[0]).max() < 1e-14
+
+
+# ---- trajectory mode (mid-circuit measurements taken when they occur, qubits released) -----------
+def _numpy_factory(n, devices=(0,), **kw):
+    return NumpyEngine(n, 1)
+
+
+def test_trajectory_compile_live_width_and_segments():
+    from qcmrf_amd import trajectory
+    C = workloads.chain(6)                                    # n = 6, m = 5, W = 12
+    segs, width, final, nclb, cregs, nsrc = trajectory.compile_trajectory(QCMRF(C, random_theta(20)))
+    assert width == 6 + 2                                     # variables + scratch + ONE recycled ancilla
+    assert len(segs) == 5 and nclb == 12
+    assert [s.measure_clbit for s in segs[:-1]] == [7, 8, 9, 10] and all(s.release for s in segs[:-1])
+    assert all(s.measure_slot == segs[0].measure_slot for s in segs[:-1])       # the same slot every time
+    assert sorted(c for _, c in final) == [0, 1, 2, 3, 4, 5, 11]
+    assert [s.n_ops for s in segs] == [2, 1, 1, 1, 1]         # init + mux, then one mux per clique
+
+
+@pytest.mark.parametrize("fusion", [0, 3])
+def test_trajectory_counts_follow_the_closed_form(models, fusion):
+    from qcmrf_amd import trajectory
+    for j in (2, 5):
+        C = models["0.5"]["GRAPHS"][j]
+        th = models["0.5"]["THETAS"][str(j)][3]
+        shots = 60000
+        vals, cnts, nclb, cregs, meta = trajectory.run_trajectories(QCMRF(C, th), shots, 11, fusion=fusion,
+                                                                    engine_factory=_numpy_factory)
+        n, m, W, dim = cf.model_shape(C)
+        assert meta["live_qubits"] == n + 2 and nclb == W and cnts.sum() == shots
+        p = cf.probabilities(C, th)
+        obs = np.zeros(p.size)
+        for v, c in zip(vals.tolist(), cnts.tolist()):
+            obs[v] += c
+        assert obs[p == 0].sum() == 0
+        sel = p * shots > 5
+        chi = ((obs[sel] - p[sel] * shots) ** 2 / (p[sel] * shots)).sum() / (sel.sum() - 1)
+        assert 0.8 < chi < 1.25
+
+
+def test_trajectory_through_the_backend_and_seeded():
+    be = QsvBackend(method="trajectory")
+    be._engine_factory = _numpy_factory
+    C = [[0, 1], [1, 2]]
+    qc = QCMRF(C, random_theta(8))
+    r1 = be.run(qc, shots=3000, seed_simulator=5).result()
+    r2 = be.run(qc, shots=3000, seed_simulator=5).result()
+    c1 = r1.get_counts()
+    assert c1 == r2.get_counts() and sum(c1.values()) == 3000 and all(len(k) == 6 for k in c1)
+    assert r1.metadata(0)["method"] == "trajectory" and r1.metadata(0)["live_qubits"] == 5
+    p = cf.probabilities(C, qc.theta)
+    assert all(p[int(k, 2)] > 0 for k in c1)
