@@ -265,7 +265,7 @@ def main():
             "metric": "shots/sec, n-qubit QCMRF circuit (fp64 statevector, ingest+evolve+sample)",
             "value": args.shots * args.steps / elapsed, "unit": "shots/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": name, "qubits": W, "shots": args.shots, "fusion": args.fusion,
                        "layout": args.layout, "state_GiB": 16.0 * 2 ** W / 2 ** 30,

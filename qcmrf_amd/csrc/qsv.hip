@@ -838,6 +838,7 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
         else { mo.tmask |= 1ull << lo.cq[k]; if (lo.cv[k]) mo.tval |= 1ull << lo.cq[k]; }
       }
       memcpy(mo.m, lo.m, sizeof mo.m);
+      if (lo.type == 2 && lo.is_x) mo.nlist = 1;           // register swap instead of arithmetic
     }
   }
   bool simple = true;

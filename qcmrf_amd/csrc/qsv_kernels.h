@@ -451,14 +451,20 @@ struct MultiOp {
 };
 struct RegPos { int pos[QSV_MULTI_MAXR]; };
 
+// thread part of a table index: bit e <- address bit pos[e]
+__device__ __forceinline__ uint32_t multi_jt(const MultiOp& op, uint64_t base) {
+  uint32_t jt = 0;
+  for (int e = 0; e < op.nlist; ++e)
+    if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
+  return jt;
+}
+
 template <int R, int B, bool SIMPLE>
 __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                               const cplx* __restrict__ lt) {
   constexpr int NP = (R > 0) ? (1 << (R - 1)) : 0;
   if (SIMPLE || op.type == 0) {
-    uint32_t jt = 0;
-    for (int e = 0; e < op.nlist; ++e)
-      if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
+    const uint32_t jt = multi_jt(op, base);
     if (SIMPLE || op.uniform) {
       const cplx* mp = lt + op.tab + 4 * jt;
       const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
@@ -483,6 +489,16 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
         a[j1] = cmad(m11, y, cmul(m10, x));
       }
     }
+  } else if (op.nlist) {   // type 2, plain X (CX / CCX / MCX with +-flags): a masked register swap, no flops
+    const bool ct = (base & op.tmask) == op.tval;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+      const bool fire = (((unsigned)j0 & op.rmask) == op.rval) && ct;
+      const cplx x = a[j0], y = a[j1];
+      a[j0] = fire ? y : x;
+      a[j1] = fire ? x : y;
+    }
   } else {   // type 2: one matrix where the controls match
     const bool ct = (base & op.tmask) == op.tval;
     const cplx m00 = make_double2(op.m[0], op.m[1]), m01 = make_double2(op.m[2], op.m[3]);
@@ -503,9 +519,7 @@ template <int R, bool SIMPLE>
 __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                            const cplx* __restrict__ lt) {
   if (SIMPLE || op.type == 1) {
-    uint32_t jt = 0;
-    for (int e = 0; e < op.nlist; ++e)
-      if (op.pos[e] >= 0) jt |= (uint32_t)((base >> op.pos[e]) & 1ull) << e;
+    const uint32_t jt = multi_jt(op, base);
     if (SIMPLE || op.uniform) {
       const cplx d = lt[op.tab + jt];
 #pragma unroll
@@ -577,15 +591,40 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
   const uint32_t base_thr = (uint32_t)ins_bits((uint64_t)threadIdx.x, ins);
   const uint64_t base = base_blk | base_thr;
   cplx* __restrict__ pblk = amp + base_blk;
+  // register-bit offsets once, in SGPRs (otherwise every one of the 2^R loads re-reads its
+  // positions from the kernel arguments and waits for them)
+  uint64_t ob[R > 0 ? R : 1];
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    ob[c] = 1ull << rp.pos[c];
+    if constexpr (R <= 4) asm volatile("" : "+s"(ob[c]));   // pinning costs registers R = 5, 6 do not have
+  }
   cplx a[1 << R];
+  if (INIT) {
 #pragma unroll
-  for (int j = 0; j < (1 << R); ++j) {
-    uint64_t off = 0;
+    for (int j = 0; j < (1 << R); ++j) {
+      uint64_t off = 0;
 #pragma unroll
-    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
-    if (INIT) a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
-    else if ((unsigned)j & zreg) a[j] = make_double2(0.0, 0.0);
-    else a[j] = (pblk + off)[base_thr];
+      for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
+      a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
+    }
+  } else if (zreg == 0) {                       // the common case: no branch between the loads
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      uint64_t off = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
+      a[j] = (pblk + off)[base_thr];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      uint64_t off = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
+      if ((unsigned)j & zreg) a[j] = make_double2(0.0, 0.0);
+      else a[j] = (pblk + off)[base_thr];
+    }
   }
   constexpr int NS = (R > 0) ? R : 1;
   for (int r = 0; r < nrounds; ++r) {
@@ -602,7 +641,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
   for (int j = 0; j < (1 << R); ++j) {
     uint64_t off = 0;
 #pragma unroll
-    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
+    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
     (pblk + off)[base_thr] = a[j];
     psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
   }
