@@ -180,7 +180,9 @@ class QsvBackend:
             from . import ir
             ph = np.exp(1j * ing.global_phase)
             ops.append(ir.op_diag([0], [ph, ph]))
-        pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"])
+        eo = opts.get("engine_options") or {}
+        lane = bool(eo.get("lane_targets", 1)) and not eo.get("zero_tracking", 0)   # lane targets need a fully populated vector
+        pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"], lane_targets=lane)
         return ing, pl
 
     def _run_trajectory(self, circuit, shots, seed, opts):
@@ -205,7 +207,7 @@ class QsvBackend:
         comm = opts["comm"] or SingleProcess()
         t0 = time.perf_counter()
         n_shards = comm.world if comm.world > 1 else len(opts["devices"])
-        ing, pl = self.compile(circuit, n_shards, **{k: opts[k] for k in ("fusion", "layout")})
+        ing, pl = self.compile(circuit, n_shards, **{k: opts[k] for k in ("fusion", "layout", "engine_options")})
         rec, data = program.encode(pl.ops)
         t1 = time.perf_counter()
 

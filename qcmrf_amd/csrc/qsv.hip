@@ -145,6 +145,7 @@ struct qsv_handle {
   int opt_nt = 0;
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   int opt_pair_variant = 0;           // experiments: see run_single
+  int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
   int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
@@ -697,6 +698,9 @@ struct PendingGroup {
   std::vector<LocalOp> ops;
   std::vector<int> targets;       // distinct target bits, in first-use order
   std::vector<int> selects;       // every table-select bit used by a table op of the group
+  std::vector<int> lane_targets;  // targets on address bits < 6, handled by wave shuffles (no register bit)
+  bool lane_mode = false;         // decided when the group opens: lane bits are really the lane id
+  bool opened = false;
   bool simple = true;             // only table ops, and no select bit is a target of the group
   size_t table_cplx = 0;
   bool init = false;              // an init write is waiting to be merged into the pass
@@ -716,25 +720,42 @@ static size_t table_cplx_of(const LocalOp& lo) {
 }
 static bool has_bit(const std::vector<int>& v, int q) { return std::find(v.begin(), v.end(), q) != v.end(); }
 
-// would the group still be "simple" (table ops only, selects disjoint from targets) with lo added?
+// does this op's target ride on a lane bit (shuffle) in group g?
+static bool is_lane_target(const PendingGroup& g, const LocalOp& lo) {
+  return g.lane_mode && lo.target >= 0 && lo.target < 6 && !has_bit(g.targets, lo.target);
+}
+
+// would the group still be "simple" (table ops only, selects disjoint from register targets)?
 static bool stays_simple(const PendingGroup& g, const LocalOp& lo) {
   if (!g.simple || lo.type > 1) return false;
   for (int q : lo.list) if (has_bit(g.targets, q) || q == lo.target) return false;
-  if (lo.target >= 0 && has_bit(g.selects, lo.target)) return false;
+  if (lo.target >= 0 && !is_lane_target(g, lo) && has_bit(g.selects, lo.target)) return false;
   return true;
 }
 static bool group_fits(const qsv_handle* h, const PendingGroup& g, const LocalOp& lo) {
   size_t nt = g.targets.size();
-  if (lo.target >= 0 && !has_bit(g.targets, lo.target)) ++nt;
+  if (is_lane_target(g, lo)) {
+    if (!has_bit(g.lane_targets, lo.target) && g.lane_targets.size() >= 6) return false;
+  } else if (lo.target >= 0 && !has_bit(g.targets, lo.target)) {
+    if (has_bit(g.lane_targets, lo.target)) return false;     // cannot be both in one pass
+    ++nt;
+  }
   // the general kernel (controls / selects on register bits, masked 2x2) is built for R <= 4
   const int rmax = stays_simple(g, lo) ? h->opt_multi_r : std::min(h->opt_multi_r, 4);
   if ((int)nt > rmax) return false;
   if (g.table_cplx + table_cplx_of(lo) > 2560 - 4) return false;  // 40 KiB of LDS tables
   return g.ops.size() < 64;
 }
-static void group_add(PendingGroup& g, LocalOp&& lo) {
+static void group_add(const qsv_handle* h, const Shard& s, PendingGroup& g, LocalOp&& lo) {
+  if (!g.opened) {
+    // lane bits are the lane id only if nothing is inserted below bit 6: no known-zero bit there
+    // (zero tracking) and a shard wide enough for 64-lane rows
+    g.opened = true;
+    g.lane_mode = h->opt_lane_targets && h->L >= 12 && s.zmask == 0;   // full wavefronts, lane id = address bits 0..5
+  }
   g.simple = stays_simple(g, lo);
-  if (lo.target >= 0 && !has_bit(g.targets, lo.target)) g.targets.push_back(lo.target);
+  if (is_lane_target(g, lo)) { if (!has_bit(g.lane_targets, lo.target)) g.lane_targets.push_back(lo.target); }
+  else if (lo.target >= 0 && !has_bit(g.targets, lo.target)) g.targets.push_back(lo.target);
   if (lo.type <= 1) for (int q : lo.list) if (!has_bit(g.selects, q)) g.selects.push_back(q);
   g.table_cplx += table_cplx_of(lo);
   g.ops.push_back(std::move(lo));
@@ -791,8 +812,9 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
     for (int b = std::min(6, h->L - 1); (int)reg.size() < want && b < h->L; ++b)
       if (!has_bit(reg, b) && (pass == 1 || (!has_bit(g.selects, b) && !((s.zmask >> b) & 1ull)))) reg.push_back(b);
   }
-  for (int b = 0; (int)reg.size() < want && b < h->L; ++b)
-    if (!has_bit(reg, b)) reg.push_back(b);
+  if (g.lane_targets.empty())
+    for (int b = 0; (int)reg.size() < want && b < h->L; ++b)
+      if (!has_bit(reg, b)) reg.push_back(b);
   const int R = (int)reg.size();
   RegPos rp;
   memset(&rp, 0, sizeof rp);
@@ -821,6 +843,10 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
     memset(&mo, 0, sizeof mo);
     mo.type = lo.type;
     mo.bit = lo.target >= 0 ? reg_index(lo.target) : 0;
+    if (lo.target >= 0 && mo.bit < 0) {                  // a lane target: wave-shuffle form
+      mo.type = lo.type == 0 ? 4 : 5;
+      mo.bit = lo.target;
+    }
     mo.uniform = 1;
     if (lo.type == 0 || lo.type == 1) {
       mo.nlist = (int)lo.list.size();
@@ -842,54 +868,79 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
     }
   }
   bool simple = true;
-  for (const MultiOp& mo : mops) if (mo.type > 1 || !mo.uniform) simple = false;
-  // rounds of R slots: slot b = [diag ops ...] + optional 2x2 gate on register bit b, program order kept
-  const int NS = std::max(R, 1);
+  for (const MultiOp& mo : mops) if ((mo.type != 0 && mo.type != 1 && mo.type != 4) || !mo.uniform) simple = false;
+  // rounds of 1 + R slots: slot 0 = list of ops without a register target (diag / phase / lane-bit
+  // gates), slot 1 + b = optional 2x2 gate on register bit b; a round runs its list first, then the
+  // bits in order.  An op joins the current round if program order allows it or if it commutes
+  // with what it would overtake (neither op's target lies in the other's support).
+  const int NS = R + 1;
   std::vector<MultiSlot> slots;
   std::vector<MultiOp> sorted;
-  sorted.reserve(mops.size());
+  sorted.reserve(mops.size() + NS);
   {
-    std::vector<std::vector<int>> slot_ops;          // op indices per slot, diag first then the gate
-    std::vector<int> slot_has;
-    int round = 0, bp = 0;
-    auto ensure = [&](int r) {
-      while ((int)slot_ops.size() < (r + 1) * NS) { slot_ops.emplace_back(); slot_has.push_back(0); }
+    auto support_mask = [&](size_t i) -> uint64_t {          // every address bit op i reads or writes
+      const LocalOp& lo = g.ops[i];
+      uint64_t m = 0;
+      if (lo.target >= 0) m |= 1ull << lo.target;
+      for (int q : lo.list) m |= 1ull << q;
+      for (int q : lo.cq) m |= 1ull << q;
+      return m;
     };
-    ensure(0);
+    auto target_mask = [&](size_t i) -> uint64_t { return g.ops[i].target >= 0 ? 1ull << g.ops[i].target : 0ull; };
+    auto commute = [&](size_t i, size_t j) -> bool {
+      return !(target_mask(i) & support_mask(j)) && !(target_mask(j) & support_mask(i));
+    };
+    struct Round { std::vector<int> list; std::vector<int> gate; std::vector<int> members; };
+    std::vector<Round> rounds(1);
+    rounds[0].gate.assign(std::max(R, 1), -1);
+    int bp = 0;                                            // gates of the current round occupy bits < bp
     for (size_t i = 0; i < mops.size(); ++i) {
       const MultiOp& mo = mops[i];
-      if (mo.type == 1 || mo.type == 3) {
-        if (bp >= NS) { ++round; bp = 0; ensure(round); }
-        slot_ops[round * NS + bp].push_back((int)i);
+      Round* cur = &rounds.back();
+      const bool is_list = mo.type == 1 || mo.type >= 3;
+      bool fits;
+      if (is_list) {
+        // the list runs before the round's gates: fine if there are none yet, or if op i commutes
+        // with every gate already placed in this round
+        fits = true;
+        for (int gi : cur->gate) if (gi >= 0 && !commute(i, (size_t)gi)) { fits = false; break; }
       } else {
-        if (mo.bit < bp) { ++round; bp = 0; ensure(round); }
-        slot_ops[round * NS + mo.bit].push_back((int)i);
-        // diagonals parked on an earlier free slot stay ahead of this gate: move them here
-        for (int b = bp; b < mo.bit; ++b) {
-          std::vector<int>& src = slot_ops[round * NS + b];
-          if (!src.empty()) {
-            std::vector<int>& dst = slot_ops[round * NS + mo.bit];
-            dst.insert(dst.begin(), src.begin(), src.end());
-            src.clear();
-          }
-        }
-        slot_has[round * NS + mo.bit] = 1;
-        bp = mo.bit + 1;
+        fits = cur->gate[mo.bit] < 0;
+        if (fits && mo.bit < bp)                           // would run before later-placed higher bits? no: lower bits run first
+          for (int gi : cur->gate) if (gi >= 0 && mops[gi].bit > mo.bit && !commute(i, (size_t)gi)) { fits = false; break; }
       }
+      if (!fits) {
+        rounds.emplace_back();
+        cur = &rounds.back();
+        cur->gate.assign(std::max(R, 1), -1);
+        bp = 0;
+      }
+      if (is_list) cur->list.push_back((int)i);
+      else { cur->gate[mo.bit] = (int)i; bp = std::max(bp, mo.bit + 1); }
     }
-    slots.resize(slot_ops.size());
-    MultiOp ident;                                    // simple passes run a gate in every slot
+    MultiOp ident;                                         // simple passes run a gate in every slot
     memset(&ident, 0, sizeof ident);
     ident.uniform = 1;
     ident.tab = (int)(tables.size() / 2);
     if (simple && R > 0) { const double id4[8] = {1, 0, 0, 0, 0, 0, 1, 0}; tables.insert(tables.end(), id4, id4 + 8); }
-    for (size_t k = 0; k < slot_ops.size(); ++k) {
-      slots[k].first = (int)sorted.size();
-      slots[k].has = slot_has[k];
-      slots[k].ndiag = (int)slot_ops[k].size() - slot_has[k];
-      slots[k].pad = 0;
-      for (int idx : slot_ops[k]) sorted.push_back(mops[idx]);
-      if (simple && R > 0 && !slot_has[k]) { ident.bit = (int)(k % NS); sorted.push_back(ident); }
+    for (const Round& rd : rounds) {
+      MultiSlot ls;
+      ls.first = (int)sorted.size();
+      ls.ndiag = (int)rd.list.size();
+      ls.has = 0;
+      ls.pad = 0;
+      for (int idx : rd.list) sorted.push_back(mops[idx]);
+      slots.push_back(ls);
+      for (int b = 0; b < R; ++b) {
+        MultiSlot gs;
+        gs.first = (int)sorted.size();
+        gs.ndiag = 0;
+        gs.has = rd.gate[b] >= 0;
+        gs.pad = 0;
+        if (rd.gate[b] >= 0) sorted.push_back(mops[rd.gate[b]]);
+        else if (simple) { ident.bit = b; sorted.push_back(ident); }
+        slots.push_back(gs);
+      }
     }
   }
   const int nrounds = (int)slots.size() / NS;
@@ -1427,7 +1478,7 @@ extern "C" int qsv_exec(qsv_handle* h, const qsv_op* ops, int n_ops, const doubl
             continue;
           }
           if (!group_fits(h, pend[k], lo)) CHK(flush_group(h, s, pend[k]));
-          group_add(pend[k], std::move(lo));
+          group_add(h, s, pend[k], std::move(lo));
         }
         break;
       }
@@ -1502,6 +1553,7 @@ extern "C" int qsv_set_option(qsv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "unroll")) h->opt_unroll = value;
   else if (!strcmp(name, "lowt_shuffle")) h->opt_lowt_shuffle = value;
   else if (!strcmp(name, "nontemporal")) h->opt_nt = value;
+  else if (!strcmp(name, "lane_targets")) h->opt_lane_targets = value != 0;
   else if (!strcmp(name, "fused_sums")) h->opt_fused_sums = value != 0;
   else if (!strcmp(name, "pair_variant")) h->opt_pair_variant = value;
   else if (!strcmp(name, "kq_mfma")) h->opt_kq_mfma = value != 0;

@@ -496,8 +496,8 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
       const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
       const bool fire = (((unsigned)j0 & op.rmask) == op.rval) && ct;
       const cplx x = a[j0], y = a[j1];
-      a[j0] = fire ? y : x;
-      a[j1] = fire ? x : y;
+      a[j0] = make_double2(fire ? y.x : x.x, fire ? y.y : x.y);
+      a[j1] = make_double2(fire ? x.x : y.x, fire ? x.y : y.y);
     }
   } else {   // type 2: one matrix where the controls match
     const bool ct = (base & op.tmask) == op.tval;
@@ -515,9 +515,65 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
   }
 }
 
+// A 2x2 gate whose target is a LANE bit (address bit < 6): the partner amplitude of every register
+// sits in lane ^ (1 << bit) of the same wavefront, so the gate is a wave shuffle plus one complex
+// multiply-add per amplitude -- no extra HBM pass and no register bit spent.  With the six lane
+// bits a pass reaches R + 6 distinct targets.  type 4: table (mux) form, type 5: masked 2x2 / X.
+template <int R, bool SIMPLE>
+__device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
+                                               const cplx* __restrict__ lt) {
+  const int lm = 1 << op.bit;
+  const bool up = (threadIdx.x >> op.bit) & 1;            // this lane holds the |1> half of the pair
+  if (SIMPLE || op.type == 4) {
+    const uint32_t jt = multi_jt(op, base);
+    if (SIMPLE || op.uniform) {
+      const cplx* mp = lt + op.tab + 4 * jt;
+      const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        cplx o;
+        o.x = __shfl_xor(a[j].x, lm, 64);
+        o.y = __shfl_xor(a[j].y, lm, 64);
+        a[j] = cmad(of, o, cmul(dg, a[j]));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        int jr = 0;
+#pragma unroll
+        for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += op.regw[c];
+        const cplx* mp = lt + op.tab + 4 * (jt + jr);
+        const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+        cplx o;
+        o.x = __shfl_xor(a[j].x, lm, 64);
+        o.y = __shfl_xor(a[j].y, lm, 64);
+        a[j] = cmad(of, o, cmul(dg, a[j]));
+      }
+    }
+  } else {   // type 5
+    const bool ct = (base & op.tmask) == op.tval;        // tmask never contains the target bit
+    const cplx dg = up ? make_double2(op.m[6], op.m[7]) : make_double2(op.m[0], op.m[1]);
+    const cplx of = up ? make_double2(op.m[4], op.m[5]) : make_double2(op.m[2], op.m[3]);
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      cplx o;
+      o.x = __shfl_xor(a[j].x, lm, 64);
+      o.y = __shfl_xor(a[j].y, lm, 64);
+      const bool fire = (((unsigned)j & op.rmask) == op.rval) && ct;
+      const cplx own = a[j];
+      const cplx gated = cmad(of, o, cmul(dg, own));
+      // component-wise selects: a select between two cplx OBJECTS takes their addresses and
+      // sends the whole register tile to scratch
+      const double rx = op.nlist ? o.x : gated.x, ry = op.nlist ? o.y : gated.y;   // nlist != 0: plain X
+      a[j] = make_double2(fire ? rx : own.x, fire ? ry : own.y);
+    }
+  }
+}
+
 template <int R, bool SIMPLE>
 __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                            const cplx* __restrict__ lt) {
+  if (op.type >= 4) { multi_lane_2x2<R, SIMPLE>(a, op, base, lt); return; }
   if (SIMPLE || op.type == 1) {
     const uint32_t jt = multi_jt(op, base);
     if (SIMPLE || op.uniform) {
@@ -542,25 +598,25 @@ __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op,
   }
 }
 
-// Schedule: the host lays the gates of a pass out in ROUNDS of R slots.  Slot b of a round holds
-// (optionally) some diagonal ops followed by (optionally) one 2x2-type gate on register bit b.
+// Schedule: the host lays the gates of a pass out in ROUNDS of 1 + R slots.  Slot 0 of a round is
+// a LIST of ops without a register target (diagonals, phases, lane-bit gates), slot 1 + b holds
+// (optionally) one 2x2-type gate on register bit b; a round runs its list, then bits 0..R-1.
 // The kernel body is therefore straight-line over b (each 2x2 path instantiated once, guarded by a
 // wave-uniform flag) inside one runtime loop over rounds -- no switch on the target bit, so every
 // amplitude is updated in place in its register (a switch made hipcc copy the whole tile per
 // case: 288 VGPRs at R = 5, spills at R = 6).
-struct MultiSlot { int first; int ndiag; int has; int pad; };   // ops[first .. first+ndiag) diag, then the gate
+struct MultiSlot { int first; int ndiag; int has; int pad; };   // list slot: ops[first .. first+ndiag); gate slot: ops[first] if has
 
 template <int R, int B, bool SIMPLE>
 __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __restrict__ ops,
                                            const MultiSlot* __restrict__ rs, uint64_t base,
                                            const cplx* __restrict__ lt) {
-  const MultiSlot sl = rs[B];
-  for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, SIMPLE>(a, ops[sl.first + d], base, lt);
   if constexpr (R > 0) {
+    const MultiSlot sl = rs[1 + B];
     // SIMPLE passes apply a gate in EVERY slot (the host fills gaps with an identity table):
     // with no branch around the update, hipcc updates the tile in place instead of keeping an
     // old and a new copy alive across the merge.
-    if (SIMPLE || sl.has) multi_2x2_bit<R, B, SIMPLE>(a, ops[sl.first + sl.ndiag], base, lt);
+    if (SIMPLE || sl.has) multi_2x2_bit<R, B, SIMPLE>(a, ops[sl.first], base, lt);
   }
 }
 
@@ -626,9 +682,13 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
       else a[j] = (pblk + off)[base_thr];
     }
   }
-  constexpr int NS = (R > 0) ? R : 1;
+  constexpr int NS = R + 1;
   for (int r = 0; r < nrounds; ++r) {
     const MultiSlot* rs = slots + r * NS;
+    {
+      const MultiSlot sl = rs[0];
+      for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, SIMPLE>(a, ops[sl.first + d], base, lt);
+    }
     multi_slot<R, 0, SIMPLE>(a, ops, rs, base, lt);
     if constexpr (R > 1) multi_slot<R, 1, SIMPLE>(a, ops, rs, base, lt);
     if constexpr (R > 2) multi_slot<R, 2, SIMPLE>(a, ops, rs, base, lt);

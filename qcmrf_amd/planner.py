@@ -52,9 +52,10 @@ def _remap(op, lay):
 
 
 LANE_BITS = 6      # address bits 0..5 are the lane id of a wavefront load (1 KiB contiguous)
+MULTI_R = 5        # register targets per k_multi pass (libqsv option multi_r)
 
 
-def choose_layout(ops, n_qubits, n_shards, layout="auto"):
+def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True):
     """layout[logical] = physical.
 
     auto, measured on MI355X (profiles/r01_multi_bits_W28.json): a k_multi pass streams at
@@ -92,8 +93,25 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto"):
     # go to the top so that the provably-zero half of the shard is one contiguous block
     quiet_u = [q for q in rest if q not in dense_first and (uniform >> q) & 1]
     quiet_z = [q for q in rest if q not in dense_first and not (uniform >> q) & 1]
-    n_lane = min(LANE_BITS, max(0, L - len(dense)), len(quiet_u))
-    order = quiet_u[:n_lane] + dense + quiet_u[n_lane:] + quiet_z   # physical 0, 1, 2, ...
+    # Dense targets beyond what the register tile holds per pass ride on LANE bits: a gate whose
+    # target is address bit < 6 is a wave shuffle inside the same k_multi pass, so a pass reaches
+    # MULTI_R register targets plus up to 6 lane targets.  Targets are taken in first-use order:
+    # per pass MULTI_R go to register positions (>= 6), that pass's share of the lane quota to lane
+    # positions -- 15 cliques need 2 passes instead of 3, 19 cliques 3 instead of 4.
+    lane_t, reg_t = [], list(dense)
+    if lane_targets and len(dense) > MULTI_R and L >= 12:
+        n_pass = max(1, -(-(len(dense) - LANE_BITS) // MULTI_R))
+        n_lane_t = min(LANE_BITS, max(0, len(dense) - MULTI_R * n_pass))
+        reg_t, k = [], 0
+        for i in range(n_pass):
+            reg_t += dense[k:k + MULTI_R]
+            k += MULTI_R
+            share = n_lane_t // n_pass + (1 if i < n_lane_t % n_pass else 0)
+            lane_t += dense[k:k + share]
+            k += share
+        reg_t += dense[k:]
+    n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - len(dense)), len(quiet_u))
+    order = quiet_u[:n_quiet_lane] + lane_t + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...
     lay = [0] * n_qubits
     for p, q in enumerate(order):
         lay[q] = p
@@ -102,7 +120,7 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto"):
     return lay
 
 
-def plan(ops, n_qubits, n_shards=1, layout="auto"):
+def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True):
     """ops on logical qubits (first op is ``init``) -> Plan with physical ops."""
     if n_shards < 1 or n_shards & (n_shards - 1):
         raise ValueError("number of shards must be a power of two")
@@ -110,7 +128,7 @@ def plan(ops, n_qubits, n_shards=1, layout="auto"):
     L = n_qubits - g
     if L < 1:
         raise ValueError("%d qubits cannot be split into %d shards" % (n_qubits, n_shards))
-    lay = choose_layout(ops, n_qubits, n_shards, layout)
+    lay = choose_layout(ops, n_qubits, n_shards, layout, lane_targets)
     P = Plan()
     P.n_qubits, P.n_shards = n_qubits, n_shards
     P.initial_layout = list(lay)
