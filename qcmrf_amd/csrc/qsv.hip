@@ -762,14 +762,14 @@ static void group_add(const qsv_handle* h, const Shard& s, PendingGroup& g, Loca
 }
 
 template <int R>
-static void launch_multi(const qsv_handle* h, const Shard& s, bool init, bool simple, uint64_t nthreads, const BitIns& ins,
+static void launch_multi(const qsv_handle* h, const Shard& s, bool init, int mode, uint64_t nthreads, const BitIns& ins,
                          const RegPos& rp, const MultiOp* dops, const MultiSlot* dslots, int nrounds,
                          const cplx* dtab, int ntab, uint64_t nonmask, double initval, unsigned zreg, double* tsums) {
   const dim3 g((unsigned)((nthreads + QSV_TPB - 1) / QSV_TPB));
   const size_t shm = (size_t)std::max(ntab, 1) * sizeof(cplx);
 #define QSV_LM(I, S) hipLaunchKernelGGL((k_multi<R, I, S>), g, dim3(QSV_TPB), shm, s.stream, s.amp, nthreads, ins, rp, dops, dslots, nrounds, dtab, ntab, nonmask, initval, zreg, tsums)
-  if (init) { if (simple) QSV_LM(true, true); else QSV_LM(true, false); }
-  else      { if (simple) QSV_LM(false, true); else QSV_LM(false, false); }
+  if (init) { if (mode == 2) QSV_LM(true, 2); else if (mode == 1) QSV_LM(true, 1); else QSV_LM(true, 0); }
+  else      { if (mode == 2) QSV_LM(false, 2); else if (mode == 1) QSV_LM(false, 1); else QSV_LM(false, 0); }
 #undef QSV_LM
 }
 
@@ -975,18 +975,33 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
     s.tile_ins = ins;
     s.tile_nblocks = nb;
   }
+  // MODE 2: simple pass whose every 2x2 table entry is RX-like (real diagonal, imaginary off-diagonal)
+  int mode = simple ? 1 : 0;
+  if (simple) {
+    bool rx = true;
+    for (const MultiOp& mo : sorted) {
+      if (mo.type != 0 && mo.type != 4) continue;
+      const size_t nent = (size_t)1 << mo.nlist;
+      for (size_t e = 0; e < nent && rx; ++e) {
+        const double* m = &tables[2 * ((size_t)mo.tab + 4 * e)];
+        if (m[1] != 0.0 || m[7] != 0.0 || m[2] != 0.0 || m[4] != 0.0) rx = false;
+      }
+      if (!rx) break;
+    }
+    if (rx) mode = 2;
+  }
   const int r = launch(h, s, QSV_K_MULTI, bytes, [&] {
     const MultiOp* o = reinterpret_cast<const MultiOp*>(dops);
     const MultiSlot* sl = reinterpret_cast<const MultiSlot*>(dslots);
     const cplx* tp = reinterpret_cast<const cplx*>(dtab);
     switch (R) {
-      case 0: launch_multi<0>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      case 1: launch_multi<1>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      case 2: launch_multi<2>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      case 3: launch_multi<3>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      case 4: launch_multi<4>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      case 5: launch_multi<5>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
-      default: launch_multi<6>(h, s, init, simple, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 0: launch_multi<0>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 1: launch_multi<1>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 2: launch_multi<2>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 3: launch_multi<3>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 4: launch_multi<4>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      case 5: launch_multi<5>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
+      default: launch_multi<6>(h, s, init, mode, nthreads, ins, rp, o, sl, nrounds, tp, ntab, nonmask, initval, zreg, tsums); break;
     }
   });
   s.tile_fresh = tsums != nullptr;

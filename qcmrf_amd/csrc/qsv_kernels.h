@@ -459,21 +459,34 @@ __device__ __forceinline__ uint32_t multi_jt(const MultiOp& op, uint64_t base) {
   return jt;
 }
 
-template <int R, int B, bool SIMPLE>
+template <int R, int B, int MODE>
 __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                               const cplx* __restrict__ lt) {
   constexpr int NP = (R > 0) ? (1 << (R - 1)) : 0;
-  if (SIMPLE || op.type == 0) {
+  if (MODE || op.type == 0) {
     const uint32_t jt = multi_jt(op, base);
-    if (SIMPLE || op.uniform) {
+    if (MODE || op.uniform) {
       const cplx* mp = lt + op.tab + 4 * jt;
       const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+      if constexpr (MODE == 2) {
+        // every matrix of the pass has a real diagonal and an imaginary off-diagonal (RX-like: the
+        // real-part-extraction blocks, [[c, -is], [-is, c]]): half the flops of a general 2x2
+        const double c0 = m00.x, s0 = m01.y, s1 = m10.y, c1 = m11.x;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-        const cplx x = a[j0], y = a[j1];
-        a[j0] = cmad(m01, y, cmul(m00, x));
-        a[j1] = cmad(m11, y, cmul(m10, x));
+        for (int p = 0; p < NP; ++p) {
+          const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+          const cplx x = a[j0], y = a[j1];
+          a[j0] = make_double2(fma(c0, x.x, -s0 * y.y), fma(c0, x.y, s0 * y.x));
+          a[j1] = make_double2(fma(c1, y.x, -s1 * x.y), fma(c1, y.y, s1 * x.x));
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
+          const cplx x = a[j0], y = a[j1];
+          a[j0] = cmad(m01, y, cmul(m00, x));
+          a[j1] = cmad(m11, y, cmul(m10, x));
+        }
       }
     } else {
 #pragma unroll
@@ -519,22 +532,31 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
 // sits in lane ^ (1 << bit) of the same wavefront, so the gate is a wave shuffle plus one complex
 // multiply-add per amplitude -- no extra HBM pass and no register bit spent.  With the six lane
 // bits a pass reaches R + 6 distinct targets.  type 4: table (mux) form, type 5: masked 2x2 / X.
-template <int R, bool SIMPLE>
+template <int R, int MODE>
 __device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                                const cplx* __restrict__ lt) {
   const int lm = 1 << op.bit;
   const bool up = (threadIdx.x >> op.bit) & 1;            // this lane holds the |1> half of the pair
-  if (SIMPLE || op.type == 4) {
+  if (MODE || op.type == 4) {
     const uint32_t jt = multi_jt(op, base);
-    if (SIMPLE || op.uniform) {
+    if (MODE || op.uniform) {
       const cplx* mp = lt + op.tab + 4 * jt;
       const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+      if constexpr (MODE == 2) {
+        const double c = dg.x, sn = of.y;                 // real diagonal, imaginary off-diagonal
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) {
-        cplx o;
-        o.x = __shfl_xor(a[j].x, lm, 64);
-        o.y = __shfl_xor(a[j].y, lm, 64);
-        a[j] = cmad(of, o, cmul(dg, a[j]));
+        for (int j = 0; j < (1 << R); ++j) {
+          const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
+          a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j) {
+          cplx o;
+          o.x = __shfl_xor(a[j].x, lm, 64);
+          o.y = __shfl_xor(a[j].y, lm, 64);
+          a[j] = cmad(of, o, cmul(dg, a[j]));
+        }
       }
     } else {
 #pragma unroll
@@ -570,13 +592,13 @@ __device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp&
   }
 }
 
-template <int R, bool SIMPLE>
+template <int R, int MODE>
 __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                            const cplx* __restrict__ lt) {
-  if (op.type >= 4) { multi_lane_2x2<R, SIMPLE>(a, op, base, lt); return; }
-  if (SIMPLE || op.type == 1) {
+  if (op.type >= 4) { multi_lane_2x2<R, MODE>(a, op, base, lt); return; }
+  if (MODE || op.type == 1) {
     const uint32_t jt = multi_jt(op, base);
-    if (SIMPLE || op.uniform) {
+    if (MODE || op.uniform) {
       const cplx d = lt[op.tab + jt];
 #pragma unroll
       for (int j = 0; j < (1 << R); ++j) a[j] = cmul(a[j], d);
@@ -607,7 +629,7 @@ __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op,
 // case: 288 VGPRs at R = 5, spills at R = 6).
 struct MultiSlot { int first; int ndiag; int has; int pad; };   // list slot: ops[first .. first+ndiag); gate slot: ops[first] if has
 
-template <int R, int B, bool SIMPLE>
+template <int R, int B, int MODE>
 __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __restrict__ ops,
                                            const MultiSlot* __restrict__ rs, uint64_t base,
                                            const cplx* __restrict__ lt) {
@@ -616,7 +638,7 @@ __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __r
     // SIMPLE passes apply a gate in EVERY slot (the host fills gaps with an identity table):
     // with no branch around the update, hipcc updates the tile in place instead of keeping an
     // old and a new copy alive across the merge.
-    if (SIMPLE || sl.has) multi_2x2_bit<R, B, SIMPLE>(a, ops[sl.first], base, lt);
+    if (MODE || sl.has) multi_2x2_bit<R, B, MODE>(a, ops[sl.first], base, lt);
   }
 }
 
@@ -624,8 +646,8 @@ __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __r
 // (amp = val where (index & nonmask) == 0): the init write and the first gate pass become one.
 // SIMPLE: every op of the pass is a table op whose select bits are all lane/block bits (the
 // shape of a fused QCMRF circuit): the general paths are compiled out.
-template <int R, bool INIT, bool SIMPLE>
-__global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
+template <int R, bool INIT, int MODE>
+__global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
                                                    BitIns ins, RegPos rp,
                                                    const MultiOp* __restrict__ ops,
                                                    const MultiSlot* __restrict__ slots, int nrounds,
@@ -687,14 +709,14 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && SIMPLE ? 2 : 1)) void k_multi(c
     const MultiSlot* rs = slots + r * NS;
     {
       const MultiSlot sl = rs[0];
-      for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, SIMPLE>(a, ops[sl.first + d], base, lt);
+      for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, MODE>(a, ops[sl.first + d], base, lt);
     }
-    multi_slot<R, 0, SIMPLE>(a, ops, rs, base, lt);
-    if constexpr (R > 1) multi_slot<R, 1, SIMPLE>(a, ops, rs, base, lt);
-    if constexpr (R > 2) multi_slot<R, 2, SIMPLE>(a, ops, rs, base, lt);
-    if constexpr (R > 3) multi_slot<R, 3, SIMPLE>(a, ops, rs, base, lt);
-    if constexpr (R > 4) multi_slot<R, 4, SIMPLE>(a, ops, rs, base, lt);
-    if constexpr (R > 5) multi_slot<R, 5, SIMPLE>(a, ops, rs, base, lt);
+    multi_slot<R, 0, MODE>(a, ops, rs, base, lt);
+    if constexpr (R > 1) multi_slot<R, 1, MODE>(a, ops, rs, base, lt);
+    if constexpr (R > 2) multi_slot<R, 2, MODE>(a, ops, rs, base, lt);
+    if constexpr (R > 3) multi_slot<R, 3, MODE>(a, ops, rs, base, lt);
+    if constexpr (R > 4) multi_slot<R, 4, MODE>(a, ops, rs, base, lt);
+    if constexpr (R > 5) multi_slot<R, 5, MODE>(a, ops, rs, base, lt);
   }
   double psum = 0.0;
 #pragma unroll

@@ -51,6 +51,20 @@ def u3(th, ph, lam):
     return _m([[c, -np.exp(1j * lam) * s], [np.exp(1j * ph) * s, np.exp(1j * (ph + lam)) * c]])
 
 
+def snap(m, tol=4e-16):
+    """Zero the real / imaginary parts of a fused matrix (stack) that are rounding residue of the
+    products that built it (|part| <= tol x the largest entry of its matrix).  The exact product of
+    e.g. H . diag . X . diag^dg . X . H has a real diagonal and an imaginary off-diagonal; the
+    residues are ~1e-17 and dropping them is an improvement, and it lets the device kernel see the
+    structure (half the flops)."""
+    m = np.array(m, dtype=np.complex128)
+    scale = np.abs(m).reshape(m.shape[:-2] + (-1,)).max(axis=-1)[..., None, None] if m.ndim >= 2 else np.abs(m).max()
+    re, im = m.real.copy(), m.imag.copy()
+    re[np.abs(re) <= tol * scale] = 0.0
+    im[np.abs(im) <= tol * scale] = 0.0
+    return re + 1j * im
+
+
 class Op:
     __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
                  "a", "b", "label")

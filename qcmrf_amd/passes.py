@@ -340,7 +340,7 @@ class _MuxWindow:
             tab[0::2], tab[1::2] = self.mats[:, 0, 0], self.mats[:, 1, 1]
             d = _reduce_diag([self.t] + self.c, tab)
             return [d] if d is not None else []
-        return [ir.op_mux(self.c, self.t, self.mats)]
+        return [ir.op_mux(self.c, self.t, ir.snap(self.mats))]
 
 
 def fuse_mux(ops, smax=8):
@@ -471,7 +471,7 @@ def _recover(qubits, U, n_ops):
         if np.abs(mats - r[:, None, None] * m0[None]).max() < _ZERO:
             d = _reduce_diag([qubits[b] for b in sel], r)
             return [ir.op_u(qubits[t], m0, label="fused")] + ([d] if d is not None else [])
-        return [ir.op_mux([qubits[b] for b in sel], qubits[t], mats)]
+        return [ir.op_mux([qubits[b] for b in sel], qubits[t], ir.snap(mats))]
     if n_ops < 3:
         return None
     return [ir.op_kq(qubits, U)]
