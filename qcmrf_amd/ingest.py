@@ -146,6 +146,104 @@ for _n in ("ch", "cy", "csx", "crx", "cry", "cu", "cu3"):
 _MCX_NAMES = ("x", "cx", "ccx", "mcx", "mcx_gray", "c3x", "c4x")
 
 
+def _conjugated_mcx_shape(definition):
+    """(ctrls, vals, target) in the definition's own qubit numbering if it is X..X . MCX . X..X
+    with the same X set on both sides, else None."""
+    data = definition.data
+    n = len(data)
+    if n < 1 or n % 2 == 0 or n > 33 or getattr(definition, "global_phase", 0):
+        return None
+    f = n // 2
+    mid, mq, _ = _unpack(data[f])
+    if mid.name not in _MCX_NAMES or getattr(mid, "condition", None) is not None:
+        return None
+    qi, _ = _bit_maps(definition)
+    if qi is None:
+        return None
+    head, tail = [], []
+    for k in range(f):
+        a, aq, _ = _unpack(data[k])
+        b, bq, _ = _unpack(data[n - 1 - k])
+        if a.name != "x" or b.name != "x" or len(aq) != 1 or len(bq) != 1:
+            return None
+        head.append(qi[id(aq[0])])
+        tail.append(qi[id(bq[0])])
+    if f and (sorted(head) != sorted(tail) or len(set(head)) != f):
+        return None
+    mq = [qi[id(b)] for b in mq]
+    ctrls, tgt = mq[:-1], mq[-1]
+    if tgt in head or any(x not in ctrls for x in head):
+        return None
+    vals = _ctrl_vals(mid, len(ctrls))
+    if f:
+        vals = [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)]
+    return ctrls, vals, tgt
+
+
+def _emit_phase_block(definition, qmap, out):
+    """A definition that is nothing but ``AND . cp . AND`` triples on one (controls, scratch, other)
+    set -- the reference's ``cU_C`` and its inverse (QCMRF.py:218-228,234) -- is a diagonal:
+    each triple puts e^{i lam} on { other = 1 and scratch xor [controls == y] = 1 }.  Emit that one
+    table instead of 3 x 2^|C| gates (exact: MCX . D . MCX with D diagonal is diagonal)."""
+    data = definition.data
+    n = len(data)
+    if n < 3 or n % 3 or getattr(definition, "global_phase", 0):
+        return False
+    qi, _ = _bit_maps(definition)
+    if qi is None:
+        return False
+    key = None
+    terms = []
+    n_src = 0
+    for k in range(0, n, 3):
+        (a, aq, _), (p, pq, _), (b, bq, _) = _unpack(data[k]), _unpack(data[k + 1]), _unpack(data[k + 2])
+        if p.name not in ("cp", "cu1") or getattr(p, "condition", None) is not None or getattr(p, "ctrl_state", None) not in (None, 1):
+            return False
+        da, db = getattr(a, "definition", None), getattr(b, "definition", None)
+        if da is None or db is None:
+            return False
+        sa, sb = _conjugated_mcx_shape(da), _conjugated_mcx_shape(db)
+        if sa is None or sb is None:
+            return False
+        # map the AND's local qubits to this definition's qubits
+        la = [qi[id(x)] for x in aq]
+        lb = [qi[id(x)] for x in bq]
+        ga = ([la[c] for c in sa[0]], sa[1], la[sa[2]])
+        gb = ([lb[c] for c in sb[0]], sb[1], lb[sb[2]])
+        if ga != gb:
+            return False
+        pl = [qi[id(x)] for x in pq]
+        ctrls, vals, tgt = ga
+        if tgt not in pl or len(pl) != 2:
+            return False
+        other = pl[0] if pl[1] == tgt else pl[1]
+        if other in ctrls or other == tgt:
+            return False
+        if key is None:
+            key = (tuple(ctrls), tgt, other)
+        elif key != (tuple(ctrls), tgt, other):
+            return False
+        terms.append((vals, _fparams(p)[0]))
+        n_src += len(da.data) + len(db.data) + 1
+    ctrls, tgt, other = key
+    qs = list(ctrls) + [tgt, other]
+    glob = [qmap[x] for x in qs]
+    if out._measured and out._measured.intersection(glob):
+        return False
+    k = len(ctrls)
+    j = np.arange(2 ** (k + 2))
+    cbits = j & (2 ** k - 1)
+    tb = (j >> k) & 1
+    ob = (j >> (k + 1)) & 1
+    ang = np.zeros(j.shape)
+    for vals, lam in terms:
+        y = sum(v << e for e, v in enumerate(vals))
+        ang += lam * (ob & (tb ^ (cbits == y)))
+    out.ops.append(ir.Op("diag", qubits=tuple(glob), table=np.exp(1j * ang)))
+    out.n_source_ops += n_src
+    return True
+
+
 def _emit_conjugated_mcx(definition, qmap, out):
     """``X..X . MCX . X..X`` with the same X set on both sides (Qiskit's AND gate with negative
     flags, QCMRF.py:224-225) is one MCX with negated controls: emit that single op."""
@@ -225,7 +323,7 @@ def _walk(circuit, qmap, cmap, out, depth):
             continue
         definition = getattr(op, "definition", None)
         if definition is not None:
-            if out.peephole and _emit_conjugated_mcx(definition, q, out):
+            if out.peephole and (_emit_phase_block(definition, q, out) or _emit_conjugated_mcx(definition, q, out)):
                 continue
             c = [cmap[ci_map[id(b)] if ci_map is not None else _index_of(circuit, b, cache)] for b in cargs]
             _walk(definition, q, c, out, depth + 1)

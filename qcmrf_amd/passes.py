@@ -179,12 +179,15 @@ class _Window:
             idx = self.perm
             self.phase = self.phase * np.where((idx & cmask) == cval, np.exp(1j * op.angle), 1.0)
         else:                                            # diag
-            bits = [self.bit(q) for q in op.qubits]
-            idx = self.perm
-            j = (idx >> bits[0]) & 1
-            for e in range(1, len(bits)):
-                j |= ((idx >> bits[e]) & 1) << e
-            self.phase = self.phase * op.table[j]
+            if list(op.qubits) == self.q:                # table index == window index: no bit shuffling
+                self.phase = self.phase * (op.table if self.is_id else op.table[self.perm])
+            else:
+                bits = [self.bit(q) for q in op.qubits]
+                idx = self.perm
+                j = (idx >> bits[0]) & 1
+                for e in range(1, len(bits)):
+                    j |= ((idx >> bits[e]) & 1) << e
+                self.phase = self.phase * op.table[j]
         self.ops.append(op)
         if not self.is_id and (k == "x" or k == "u"):
             self.is_id = bool((self.perm == np.arange(self.perm.size)).all())
@@ -314,15 +317,21 @@ class _MuxWindow:
                 tab[jj] = np.exp(1j * op.angle)
             else:
                 tab = op.table
-            bits = [(-1 if q == self.t else self._ctrl_bit(q)) for q in qs]
-            j = np.arange(self.mats.shape[0])
-            d = np.empty((j.size, 2), dtype=np.complex128)
-            for tv in (0, 1):
-                k = np.zeros(j.shape, dtype=np.int64)
-                for pos, b in enumerate(bits):
-                    bitval = tv if b < 0 else ((j >> b) & 1)
-                    k |= bitval << pos
-                d[:, tv] = tab[k]
+            if qs[-1] == self.t and qs[:-1] == self.c[:len(qs) - 1] and (len(qs) - 1 == len(self.c) or not self.c):
+                # table index = (select bits in window order, target as MSB): a reshape, no gather
+                for q in qs[:-1]:
+                    self._ctrl_bit(q)
+                d = np.asarray(tab).reshape(2, -1).T
+            else:
+                bits = [(-1 if q == self.t else self._ctrl_bit(q)) for q in qs]
+                j = np.arange(self.mats.shape[0])
+                d = np.empty((j.size, 2), dtype=np.complex128)
+                for tv in (0, 1):
+                    k = np.zeros(j.shape, dtype=np.int64)
+                    for pos, b in enumerate(bits):
+                        bitval = tv if b < 0 else ((j >> b) & 1)
+                        k |= bitval << pos
+                    d[:, tv] = tab[k]
             self.mats = d[:, :, None] * self.mats          # diag(d0, d1) @ M
         self.ops.append(op)
 
@@ -518,7 +527,16 @@ class _DenseWindow:
             self.mark = (len(self.ops), self.U.copy(), list(self.q))
 
 
+_DENSE_KINDS = ("u", "x", "diag", "mcphase", "mux", "kq")
+
+
 def fuse_dense(ops, kmax=5):
+    # nothing to gain unless two neighbouring gates fit one window together
+    for a, b in zip(ops, ops[1:]):
+        if a.kind in _DENSE_KINDS and b.kind in _DENSE_KINDS and len(set(a.support()) | set(b.support())) <= kmax:
+            break
+    else:
+        return list(ops)
     out = []
     pending = list(ops)
     pos = 0
