@@ -270,6 +270,7 @@ def main():
             "config": {"workload": name, "qubits": W, "shots": args.shots, "fusion": args.fusion,
                        "layout": args.layout, "state_GiB": 16.0 * 2 ** W / 2 ** 30,
                        "sweeps_per_step": sum(a["launches"] for k, a in agg.items() if k != "prob") // args.steps,
+                       "gates_per_step_on_device": meta["n_device_ops"] - 1,
                        "source_gates": meta["n_source_ops"], "exchanges_per_step": meta["n_exchanges"],
                        "parallelism": "amplitude shards by high qubit x%d" % (args.virtual_shards or args.gpus)
                                       + (" (virtual shards on one device)" if args.virtual_shards else "")},

@@ -980,6 +980,7 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
   if (simple) {
     bool rx = true;
     for (const MultiOp& mo : sorted) {
+      if (mo.type == 1) { rx = false; break; }           // a complex diagonal does not fit the RX-like form
       if (mo.type != 0 && mo.type != 4) continue;
       const size_t nent = (size_t)1 << mo.nlist;
       for (size_t e = 0; e < nent && rx; ++e) {
@@ -990,7 +991,8 @@ static int flush_group(qsv_handle* h, Shard& s, PendingGroup& g, bool final_pass
     }
     if (rx) mode = 2;
   }
-  const int r = launch(h, s, QSV_K_MULTI, bytes, [&] {
+  // the init-fused pass (write only) is a different kernel instantiation: accounted on its own
+  const int r = launch(h, s, init ? QSV_K_MULTI_INIT : QSV_K_MULTI, bytes, [&] {
     const MultiOp* o = reinterpret_cast<const MultiOp*>(dops);
     const MultiSlot* sl = reinterpret_cast<const MultiSlot*>(dslots);
     const cplx* tp = reinterpret_cast<const cplx*>(dtab);

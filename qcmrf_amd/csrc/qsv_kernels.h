@@ -542,12 +542,15 @@ __device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp&
     if (MODE || op.uniform) {
       const cplx* mp = lt + op.tab + 4 * jt;
       const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+      // chunks of 4 registers with a scheduling fence in between: left alone, hipcc hoists all
+      // 2^R x 2 shuffles ahead of the arithmetic and spills the tile (R = 5: +19 % HBM traffic)
       if constexpr (MODE == 2) {
         const double c = dg.x, sn = of.y;                 // real diagonal, imaginary off-diagonal
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j) {
           const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
           a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
@@ -556,6 +559,7 @@ __device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp&
           o.x = __shfl_xor(a[j].x, lm, 64);
           o.y = __shfl_xor(a[j].y, lm, 64);
           a[j] = cmad(of, o, cmul(dg, a[j]));
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else {
@@ -595,6 +599,36 @@ __device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp&
 template <int R, int MODE>
 __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                            const cplx* __restrict__ lt) {
+  if constexpr (MODE >= 1) {
+    // ONE update path for every list op of a simple pass: new = dg * own + of * partner, where a
+    // diagonal is the special case of = 0.  Branching between two whole-tile updates (diagonal vs
+    // lane gate) made hipcc keep both results alive: +70 VGPRs at R = 5, i.e. spills that showed up
+    // as +19 % HBM traffic in the PMC counters.
+    const uint32_t jt = multi_jt(op, base);
+    const bool lane_op = op.type == 4;
+    const int lm = lane_op ? (1 << op.bit) : 1;
+    const bool up = lane_op && ((threadIdx.x >> op.bit) & 1);
+    const cplx* mp = lt + op.tab + (lane_op ? 4 * jt : jt);
+    const cplx dg = lane_op ? (up ? mp[3] : mp[0]) : mp[0];
+    const cplx of = lane_op ? (up ? mp[2] : mp[1]) : make_double2(0.0, 0.0);
+    if constexpr (MODE == 2) {
+      const double c = dg.x, sn = of.y;                   // RX-like tables only (host guarantees: no diagonals)
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
+        a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        cplx o;
+        o.x = __shfl_xor(a[j].x, lm, 64);
+        o.y = __shfl_xor(a[j].y, lm, 64);
+        a[j] = cmad(of, o, cmul(dg, a[j]));
+      }
+    }
+    return;
+  }
   if (op.type >= 4) { multi_lane_2x2<R, MODE>(a, op, base, lt); return; }
   if (MODE || op.type == 1) {
     const uint32_t jt = multi_jt(op, base);
