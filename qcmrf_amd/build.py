@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libqsv.so")
 SOURCES = ["qsv.hip"]
-DEPENDS = ["qsv.hip", "qsv_kernels.h", os.path.join("..", "..", "include", "qsv.h")]
+DEPENDS = ["qsv.hip", "qsv_kernels.h", "qsv_gates.inc", "qsv_multi.inc", "qsv_layout.inc", "qsv_measure.inc",
+           "qsv_exec.inc", os.path.join("..", "..", "include", "qsv.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -61,7 +61,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "qcmrf_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "qsv_ref" not in txt, f
