@@ -383,3 +383,33 @@ def test_trajectory_mode_small_and_beyond_statevector_reach(be, models):
         both = ((idx >> (21 - v0)) & 1) & ((idx >> (20 - v0)) & 1)
         assert abs((xs[:, v0] * xs[:, v0 + 1]).mean() - pg[both == 1].sum()) < 5 * 0.5 / np.sqrt(len(xs)) + 1e-3
     tb.close()
+
+
+@pytest.mark.parametrize("fusion", [0, 3])
+def test_random_circuit_w20_against_c_oracle(be, fusion):
+    """a 20-qubit random circuit (all gate kinds, targets on lane / register / block bits) against
+    the plain-C gate-level oracle: the general k_multi paths at a size where every lane of every
+    wavefront is live"""
+    from test_host_logic import rand_circuit
+    from oracle import cref
+    nq = 20
+    qc = rand_circuit(nq, 160, 2024)
+    ref = cref.RefState(nq)
+    for ci in qc.data:
+        name, p = ci.operation.name, ci.operation.params
+        q = [qc.find_bit(b).index for b in ci.qubits]
+        if name == "x": ref.apply_mcx([], q[0])
+        elif name in sv.MATS: ref.apply_1q(q[0], sv.MATS[name])
+        elif name == "cx": ref.apply_mcx([q[0]], q[1])
+        elif name == "ccx": ref.apply_mcx(q[:2], q[2])
+        elif name == "rz": ref.apply_1q(q[0], sv.rz(p[0]))
+        elif name == "ry": ref.apply_1q(q[0], sv.ry(p[0]))
+        elif name == "cp": ref.apply_mcphase(q, p[0])
+        elif name == "cz": ref.apply_mcphase(q, np.pi)
+        elif name == "swap":
+            ref.apply_mcx([q[0]], q[1]); ref.apply_mcx([q[1]], q[0]); ref.apply_mcx([q[0]], q[1])
+        else: raise AssertionError(name)
+    for opts in ({}, {"zero_tracking": 1}, {"lane_targets": 0}, {"multi_r": 3}):
+        amp, meta = run_state(be, qc, fusion=fusion, engine_options=opts)
+        assert np.abs(amp - ref.state).max() < 1e-12, (fusion, opts)
+    be.run(qc, shots=0, engine_options={"zero_tracking": 0, "lane_targets": 1, "multi_r": 5})
