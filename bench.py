@@ -123,6 +123,7 @@ def gate_microbench(args):
         k, v = o.split("=")
         eng.set_option(k, int(v))
     eng.init_uniform((1 << W) - 1)
+    eng.set_option("cache_sums", 0)                 # the norm pass below must really run every time
     A = float(2 ** W)
     cases = []
     for t in range(W):

@@ -146,6 +146,7 @@ struct qsv_handle {
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   int opt_pair_variant = 0;           // experiments: see run_single
   int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
+  int opt_cache_sums = 1;             // 0: every norm / sample recomputes the block sums (benchmarks)
   int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
