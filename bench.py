@@ -11,10 +11,13 @@ exactly the call /root/reference/run_experiment.py:56-57 makes.  The circuit is 
 outside the timed region; the state vector lives in HBM throughout (nothing crosses PCIe except
 the gate tables, a few KB, and the sampled outcomes).
 
-Workload by N (BASELINE.json configs; --qubits overrides with a grid MRF of that width):
-    N=1    configs[2]  28-qubit 2x6-grid MRF minus last edge        4 GiB state
-    N=2,4  configs[3]  31-qubit random-graph MRF G(10,20)           32 GiB, 16 / 8 GiB shards
-    N=8    configs[4]  34-qubit 2x7-grid MRF                        256 GiB, 32 GiB shards
+Workload: ONE circuit for every N (strong scaling) -- BASELINE.json configs[4], the 34-qubit
+2x7-grid MRF, 256 GiB of complex128 amplitudes: it fits the 288 GiB of a single MI355X, so
+value(8) / value(1) is the 1 -> 8 GPU speed-up "at 34 qubits" of the north star (shards of
+256 / 128 / 64 / 32 GiB at N = 1 / 2 / 4 / 8).  On a smaller card the widest grid MRF one device
+holds is used instead (same rule on every rank).  --config i / --qubits W override.  At N = 1 the
+line also carries ``other_configs``: configs[2] (28 qubits, the HBM-roofline config) and
+configs[1] (20 qubits), same step definition, not part of ``value``.
 theta = -halfnorm.rvs(scale=0.5), seed 1984; 4096 shots; seed_simulator 1984.
 
 The JSON line carries ``roofline`` (dominant kernel, HIP-event timed on its launch stream over
@@ -60,25 +63,55 @@ def parse():
     return ap.parse_args()
 
 
-def workload(args):
+CPU_SAMPLE_QUBITS = 28          # 4 GiB: the widest state the plain-C CPU leg is timed on (about 25 s)
+
+
+def workload(args, hbm_total):
+    """One circuit for every N (strong scaling): BASELINE configs[4], the 34-qubit grid MRF
+    (256 GiB of amplitudes), whenever ONE device can hold it -- an MI355X has 288 GiB -- so that
+    value(N) / value(1) is the 1 -> N speed-up "at 34 qubits" the north star asks for; otherwise the
+    widest grid MRF one device holds.  --config / --qubits override."""
     from qcmrf_amd import workloads as wl
     if args.qubits:
         C = wl.for_width(args.qubits)
         name = "grid MRF, W=%d (n=%d, m=%d)" % (args.qubits, wl.width(C) - len(C) - 1, len(C))
+    elif args.config:
+        name, C = wl.baseline_config(args.config)
     else:
-        name, C = wl.baseline_config(args.config or {1: 2, 2: 3, 4: 3, 8: 4}.get(args.gpus, 2))
+        W = 34
+        while W > 20 and 16 * 2 ** W + (8 << 30) > hbm_total:
+            W -= 1
+        if W == 34:
+            name, C = wl.baseline_config(4)
+        else:
+            C = wl.for_width(W)
+            name = "grid MRF, W=%d (n=%d, m=%d): widest that fits one device" % (W, wl.width(C) - len(C) - 1, len(C))
     return name, C, wl.theta_halfnorm(wl.dimension(C))
 
 
 # --------------------------------------------------------------------------------------------
 def cpu_baseline(cliques, theta, shots, budget_s):
-    """Plain-C oracle (OpenMP, all host threads) on the UNFUSED reference-order gate stream of the
-    same circuit: the n initial H gates plus as many whole clique blocks as fit the time budget,
-    extrapolated to all m blocks (every block has the same gate mix).  Reported, not a target."""
+    """Plain-C oracle (OpenMP, all host threads) on the UNFUSED reference-order gate stream: the n
+    initial H gates plus as many whole clique blocks as fit the time budget, extrapolated to all m
+    blocks (every block has the same gate mix).  A circuit wider than CPU_SAMPLE_QUBITS does not
+    fit a sensible host sample: the 28-qubit config is timed instead and scaled by the gate count
+    and by 2^(W-28) (every gate is one memory-bound sweep of the 2^W vector).  Reported, not a target."""
     from oracle import cref, gate_stream as gs, closed_form as cf
+    from qcmrf_amd import workloads as wl
     cref.build()
     cref.set_threads(cref.host_threads())          # affinity / cgroup share, not the box's 256 logical CPUs
     n, m, W, dim = cf.model_shape(cliques)
+    scale, note = 1.0, ""
+    if W > CPU_SAMPLE_QUBITS:
+        n_gates_full = len(gs.reference_stream(cliques, theta, with_measurements=False))
+        _, cliques = wl.baseline_config(2)
+        theta = wl.theta_halfnorm(wl.dimension(cliques))
+        n, m, W0, dim = cf.model_shape(cliques)
+        n_gates_sample = len(gs.reference_stream(cliques, theta, with_measurements=False))
+        scale = n_gates_full / n_gates_sample * 2.0 ** (W - W0)
+        note = ("; the W=%d state (%.0f GiB) does not fit a host sample, so the 28-qubit config was timed and scaled by "
+                "gates %d/%d x 2^%d = %.1fx" % (W, 16 * 2.0 ** W / 2 ** 30, n_gates_full, n_gates_sample, W - W0, scale))
+        W = W0
     ops = gs.reference_stream(cliques, theta, with_measurements=False)
     # split into the H prologue and per-clique blocks (each starts with the H on its ancilla)
     starts = [i for i, op in enumerate(ops) if op[0] == "h" and op[1] > n]
@@ -98,12 +131,12 @@ def cpu_baseline(cliques, theta, shots, budget_s):
     t0 = time.perf_counter()
     st.norm()
     t_prob = time.perf_counter() - t0
-    est = t_h + t_blocks / done * m + t_prob
+    est = (t_h + t_blocks / done * m + t_prob) * scale
     return {"value": shots / est, "unit": "shots/s", "cores": st.threads(), "kind": "port",
             "sample": "W=%d state (%.0f MiB) on host; %d H gates + %d of %d clique blocks (%d of %d gates) + norm pass "
-                      "timed = %.1f s, extrapolated by block count to %.1f s per circuit; unfused reference-order "
-                      "stream; plain-C OpenMP restatement (Qiskit Aer not installable offline)"
-                      % (W, 16 * 2 ** W / 2 ** 20, n, done, m, starts[done], len(ops), t_h + t_blocks + t_prob, est)}
+                      "timed = %.1f s, extrapolated to %.1f s per circuit; unfused reference-order "
+                      "stream; plain-C OpenMP restatement (Qiskit Aer not installable offline)%s"
+                      % (W, 16 * 2 ** W / 2 ** 20, n, done, m, starts[done], len(ops), t_h + t_blocks + t_prob, est, note)}
 
 
 # --------------------------------------------------------------------------------------------
@@ -162,6 +195,53 @@ def gate_microbench(args):
 
 
 # --------------------------------------------------------------------------------------------
+def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=()):
+    """W warm-up runs, then exactly `steps` runs bracketed by barrier + device sync on both sides;
+    elapsed = max over ranks.  Returns the per-kernel HIP-event aggregation as well."""
+    for i in range(warmup):
+        backend.run(qc, shots=shots, seed_simulator=seed0 + i).result()
+    for o in options:
+        k, v = o.split("=")
+        backend.last_engine.set_option(k, int(v))
+    comm.barrier()
+    backend.last_engine.sync()
+    t0 = time.perf_counter()
+    agg = {}
+    t = {"compile": 0.0, "evolve": 0.0, "sample": 0.0}
+    for i in range(steps):
+        res = backend.run(qc, shots=shots, seed_simulator=seed0 + warmup + i, profile=True).result()
+        meta = res.metadata(0)
+        for k in t:
+            t[k] += meta["time_" + k]
+        for k, v in meta["stats"]["kinds"].items():
+            a = agg.setdefault(k, {"launches": 0, "bytes": 0.0, "ms": 0.0})
+            for f in a:
+                a[f] += v[f]
+    backend.last_engine.sync()
+    comm.barrier()
+    elapsed = max(comm.allgather(time.perf_counter() - t0))
+    counts = res.get_counts()
+    assert sum(counts.values()) == shots
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    return {"elapsed": elapsed, "meta": meta, "agg": agg, "dom": dom,
+            "breakdown_ms": {k: v / steps * 1e3 for k, v in t.items()},
+            "kernels": {k: {"launches_per_step": a["launches"] / steps, "avg_ms": a["ms"] / a["launches"],
+                            "GBps": a["bytes"] / a["ms"] / 1e6 if a["ms"] > 0 else None} for k, a in agg.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": d["bytes"] / d["ms"] / 1e6,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBPS,
+                         "traffic": None, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                         "avg_launch_ms": d["ms"] / d["launches"], "rank": 0}}
+
+
+def pmc_traffic(dom, W):
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(tfile)).get("k_" + dom, {}).get("hbm_bytes_per_launch_W%d" % W)
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -176,51 +256,25 @@ def main():
     from qcmrf_amd import _lib, QCMRF
     from qcmrf_amd.backend import QsvBackend
     from qcmrf_amd.comm import SingleProcess, TorchDistComm
+    from qcmrf_amd import workloads as wl
     _lib.load()
+    n_dev = _lib.device_count()          # initialises /opt/rocm's HIP runtime before torch brings its own copy in
 
     if args.gates:
         gate_microbench(args)
         return
 
     comm = TorchDistComm("gloo") if world > 1 else SingleProcess()
-    name, cliques, theta = workload(args)
+    device = local_rank % max(1, n_dev)
+    hbm_total = comm.bcast(_lib.device_memory(device)[1] if rank == 0 else None)
+    name, cliques, theta = workload(args, hbm_total)
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
-                         device=local_rank % max(1, _lib.device_count()),
-                         devices=(0,) * max(1, args.virtual_shards))
+                         device=device, devices=(0,) * max(1, args.virtual_shards))
 
-    def step(i, profile=False):
-        res = backend.run(qc, shots=args.shots, seed_simulator=1984 + i, profile=profile).result()
-        return res
-
-    for i in range(args.warmup):
-        step(i)
-    if backend.last_engine is not None:
-        for o in args.option:
-            k, v = o.split("=")
-            backend.last_engine.set_option(k, int(v))
-    comm.barrier()
-    backend.last_engine.sync() if backend.last_engine else None
-    t0 = time.perf_counter()
-    agg = {}
-    t_compile = t_evolve = t_sample = 0.0
-    for i in range(args.steps):
-        res = step(args.warmup + i, profile=True)
-        meta = res.metadata(0)
-        t_compile += meta["time_compile"]
-        t_evolve += meta["time_evolve"]
-        t_sample += meta["time_sample"]
-        for k, v in meta["stats"]["kinds"].items():
-            a = agg.setdefault(k, {"launches": 0, "bytes": 0.0, "ms": 0.0})
-            for f in a:
-                a[f] += v[f]
-    backend.last_engine.sync()
-    comm.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max(comm.allgather(elapsed))
-    counts = res.get_counts()
-    assert sum(counts.values()) == args.shots
+    main_leg = timed_leg(backend, comm, qc, args.shots, args.steps, args.warmup, options=args.option)
+    elapsed, meta, agg = main_leg["elapsed"], main_leg["meta"], main_leg["agg"]
 
     # untimed-for-`value` extra legs (every rank takes part; reported under "variants")
     variants = {}
@@ -250,42 +304,44 @@ def main():
                 2, circuit=transpile(qc), fusion=args.fusion)
         backend.run(qc, shots=16, engine_options={"zero_tracking": 0})
 
+    # N = 1: the other single-GPU configs of BASELINE.json, same step definition (not part of `value`)
+    other = {}
+    if world == 1 and not args.no_variants and not (args.qubits or args.config or args.virtual_shards):
+        for ci in (2, 1):
+            oname, oc = wl.baseline_config(ci)
+            oq = QCMRF(oc, wl.theta_halfnorm(wl.dimension(oc)))
+            lg = timed_leg(backend, comm, oq, args.shots, max(args.steps, 10), 2)
+            rf = lg["roofline"]
+            rf["traffic"] = pmc_traffic(lg["dom"], oq.num_qubits)
+            other[oname] = {"shots_per_s": args.shots * max(args.steps, 10) / lg["elapsed"],
+                            "ms_per_step": lg["elapsed"] / max(args.steps, 10) * 1e3,
+                            "breakdown_ms": lg["breakdown_ms"], "kernels": lg["kernels"], "roofline": rf}
+
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        d = agg[dom]
-        achieved = d["bytes"] / d["ms"] / 1e6                 # GB/s, per launch average
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("k_" + dom, {}).get("hbm_bytes_per_launch_W%d" % W)
-            except Exception:
-                traffic = None
+        roof = main_leg["roofline"]
+        roof["traffic"] = pmc_traffic(main_leg["dom"], W)
         line = {
             "metric": "shots/sec, n-qubit QCMRF circuit (fp64 statevector, ingest+evolve+sample)",
             "value": args.shots * args.steps / elapsed, "unit": "shots/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": name, "qubits": W, "shots": args.shots, "fusion": args.fusion,
                        "layout": args.layout, "state_GiB": 16.0 * 2 ** W / 2 ** 30,
+                       "shard_GiB": 16.0 * 2 ** W / 2 ** 30 / max(args.virtual_shards, args.gpus),
                        "sweeps_per_step": sum(a["launches"] for k, a in agg.items() if k != "prob") // args.steps,
                        "gates_per_step_on_device": meta["n_device_ops"] - 1,
                        "source_gates": meta["n_source_ops"], "exchanges_per_step": meta["n_exchanges"],
                        "parallelism": "amplitude shards by high qubit x%d" % (args.virtual_shards or args.gpus)
                                       + (" (virtual shards on one device)" if args.virtual_shards else "")},
-            "breakdown_ms": {"compile": t_compile / args.steps * 1e3, "evolve": t_evolve / args.steps * 1e3,
-                             "sample": t_sample / args.steps * 1e3},
-            "kernels": {k: {"launches_per_step": a["launches"] / args.steps,
-                            "avg_ms": a["ms"] / a["launches"],
-                            "GBps": a["bytes"] / a["ms"] / 1e6 if a["ms"] > 0 else None} for k, a in agg.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                         "avg_launch_ms": d["ms"] / d["launches"], "rank": 0},
+            "breakdown_ms": main_leg["breakdown_ms"],
+            "kernels": main_leg["kernels"],
+            "roofline": roof,
         }
         line["variants"] = variants
+        if other:
+            line["other_configs"] = other
         if args.gpus == 1 and not args.no_cpu:
             backend.close()
             line["cpu_baseline"] = cpu_baseline(cliques, theta, args.shots, args.cpu_seconds)

@@ -70,6 +70,10 @@ typedef struct {
 /* number of visible HIP devices (<0 on error) */
 int qsv_device_count(void);
 
+/* HBM of one device in bytes (free now / total): lets the caller size a state vector to the
+ * card (2^34 complex128 = 256 GiB fits the 288 GiB of one MI355X). */
+int qsv_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes);
+
 /* One process drives n_devices shards (n_devices a power of two).  device_ids[i] is the HIP
  * device of shard i; repeating an id places several ("virtual") shards on one GPU.
  * Replaces: the state allocation inside Aer's run() (run_experiment.py:56). */

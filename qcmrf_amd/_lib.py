@@ -83,6 +83,7 @@ SIGNATURES = {
     "qsv_set_option": (_i, [_vp, C.c_char_p, _i]),
     "qsv_last_error": (C.c_char_p, []),
     "qsv_version": (C.c_char_p, []),
+    "qsv_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 _lib = None
@@ -140,6 +141,13 @@ def device_count():
     if n < 0:
         _raise(n)
     return n
+
+
+def device_memory(device=0):
+    """(free, total) bytes of HBM on one device"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _chk(load().qsv_device_memory(int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def comm_unique_id():

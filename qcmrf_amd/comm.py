@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import os
 import pickle
+import sys
 
 
 class SingleProcess:
@@ -33,7 +34,16 @@ class TorchDistComm:
         self._dist = dist
         if init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend=backend)
+            # gloo announces its connections with printf: keep that off stdout, which belongs to
+            # the caller (bench.py prints exactly one JSON line there)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                dist.init_process_group(backend=backend)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
 

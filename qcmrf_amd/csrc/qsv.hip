@@ -164,7 +164,9 @@ static unsigned grid_for(const qsv_handle* h, const Shard& s, uint64_t work, uin
   uint64_t need = (work + per_block - 1) / per_block;
   uint64_t cap = (uint64_t)s.n_cu * (uint64_t)h->opt_blocks_per_cu;
   if (need < 1) need = 1;
-  return (unsigned)std::min<uint64_t>(std::min(need, cap), 0x7fffffffull);
+  // HIP rejects a launch whose gridDim.x * blockDim.x reaches 2^32 (hit by a 256 GiB shard:
+  // 2^34 amplitudes / 4 per thread); every kernel sized through here has a grid-stride loop
+  return (unsigned)std::min<uint64_t>(std::min(need, cap), (1ull << 24) - 1ull);
 }
 
 // device copy of a small host table, asynchronous on the shard stream
@@ -259,6 +261,18 @@ extern "C" int qsv_device_count(void) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return fail(QSV_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
   return n;
+}
+
+extern "C" int qsv_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes) {
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(QSV_E_BADARG, "device id %d not in [0,%d)", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return QSV_OK;
 }
 
 static int create_common(int n_qubits, int P, qsv_handle** out, qsv_handle** hh) {
