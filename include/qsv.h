@@ -172,11 +172,15 @@ enum {
   QSV_OP_MCPHASE, QSV_OP_MUX, QSV_OP_KQ, QSV_OP_SWAP
 };
 
+/* scheduling hint from the planner: close the current multi-gate pass before this gate (the
+ * result does not depend on it; it only decides which gates share one sweep of the shard) */
+#define QSV_OPF_NEW_PASS 1
+
 typedef struct {
   int32_t  kind;                   /* QSV_OP_*                                             */
   int32_t  target;                 /* target qubit (1Q, MCX, MUX)                          */
   int32_t  n;                      /* number of controls / qubits in qubits[]              */
-  int32_t  pad;
+  int32_t  flags;                  /* QSV_OPF_*                                            */
   int32_t  qubits[QSV_MAX_CTRL];   /* controls, or qubit list (DIAG, KQ), or swap a-list   */
   int32_t  vals[QSV_MAX_CTRL];     /* control values, or swap b-list                       */
   uint64_t data_off;               /* offset in doubles into `data` (matrix / table)       */

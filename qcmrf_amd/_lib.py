@@ -22,6 +22,7 @@ K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "e
 K_COUNT = len(K_NAMES)
 
 OP_INIT_ZERO, OP_INIT_UNIFORM, OP_1Q, OP_MCX, OP_DIAG, OP_MCPHASE, OP_MUX, OP_KQ, OP_SWAP = range(9)
+OPF_NEW_PASS = 1
 
 
 class KindStats(C.Structure):
@@ -34,12 +35,12 @@ class Stats(C.Structure):
 
 
 class QsvOp(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("target", C.c_int32), ("n", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("kind", C.c_int32), ("target", C.c_int32), ("n", C.c_int32), ("flags", C.c_int32),
                 ("qubits", C.c_int32 * MAX_CTRL), ("vals", C.c_int32 * MAX_CTRL),
                 ("data_off", C.c_uint64), ("mask", C.c_uint64), ("angle", C.c_double)]
 
 
-OP_DTYPE = np.dtype([("kind", "<i4"), ("target", "<i4"), ("n", "<i4"), ("pad", "<i4"),
+OP_DTYPE = np.dtype([("kind", "<i4"), ("target", "<i4"), ("n", "<i4"), ("flags", "<i4"),
                      ("qubits", "<i4", (MAX_CTRL,)), ("vals", "<i4", (MAX_CTRL,)),
                      ("data_off", "<u8"), ("mask", "<u8"), ("angle", "<f8")])
 assert OP_DTYPE.itemsize == C.sizeof(QsvOp)

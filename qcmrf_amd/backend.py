@@ -204,7 +204,8 @@ class QsvBackend:
             ops.append(ir.op_diag([0], [ph, ph]))
         eo = opts.get("engine_options") or {}
         lane = bool(eo.get("lane_targets", 1)) and not eo.get("zero_tracking", 0)   # lane targets need a fully populated vector
-        pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"], lane_targets=lane)
+        pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"], lane_targets=lane,
+                          dyn_lanes=int(eo.get("dyn_lanes", planner.DYN_LANES)))
         return ing, pl
 
     def _run_trajectory(self, circuit, shots, seed, opts):

@@ -118,6 +118,7 @@ struct Shard {
   bool tile_valid = false, tile_fresh = false;
   int tile_R = 0;
   RegPos tile_rp;
+  LanePos tile_lp;
   BitIns tile_ins;
   uint64_t tile_nblocks = 0;
   uint64_t* d_sblk = nullptr;    // sampling scratch (block index, residual, result per shot)
@@ -146,6 +147,9 @@ struct qsv_handle {
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   int opt_pair_variant = 0;           // experiments: see run_single
   int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
+  int opt_pass_hints = 1;             // honour QSV_OPF_NEW_PASS (planner-chosen pass boundaries)
+  int opt_lane_map = 1;               // access pattern of passes without borrowed lanes: 0 plain, 1 auto, else explicit 5-bit fields
+  int opt_dyn_lanes = 3;              // lane bits 3..5 lent per pass to targets anywhere below bit 28 (0..3)
   int opt_cache_sums = 1;             // 0: every norm / sample recomputes the block sums (benchmarks)
   int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores

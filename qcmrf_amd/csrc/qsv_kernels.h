@@ -450,6 +450,25 @@ struct MultiOp {
   double m[8];                    // type 2: 2x2 row-major {re,im}; type 3: m[0..1] = phase
 };
 struct RegPos { int pos[QSV_MULTI_MAXR]; };
+// Address bit carried by lane bits 3, 4, 5 of a wavefront.  Lane bits 0..2 are always address
+// bits 0..2 (8 lanes x 16 B = one 128-byte line per lane group); the upper three default to
+// {3,4,5} (a wave load = 1 KiB contiguous) or are lent, per pass, to target qubits anywhere below
+// bit 28: the gate on such a bit is then a wave shuffle like any other lane-bit gate, and a wave
+// load becomes 8 separate 128-byte lines.  `ins` of the pass holds these positions too.
+struct LanePos { int pos[3]; };
+
+// pos[0] < 0: plain mapping -- thread index bits fill the non-inserted address bits in order.
+// thread part / block part of a tile base address; thread index t = wave:2 | lane:6
+__device__ __forceinline__ uint32_t tile_base_thr(uint32_t t, const BitIns& ins, const LanePos& lp) {
+  if (lp.pos[0] < 0) return (uint32_t)ins_bits((uint64_t)t, ins);
+  const uint32_t u = ((t >> 6) << 3) | (t & 7u);
+  return (uint32_t)ins_bits((uint64_t)u, ins) | (((t >> 3) & 1u) << lp.pos[0]) | (((t >> 4) & 1u) << lp.pos[1]) |
+         (((t >> 5) & 1u) << lp.pos[2]);
+}
+__device__ __forceinline__ uint64_t tile_base_blk(uint64_t block, const BitIns& ins, const LanePos& lp) {
+  if (lp.pos[0] < 0) return ins_bits(block * QSV_TPB, ins);
+  return ins_bits(block << 5, ins);          // QSV_TPB / 64 waves x 8 low lanes per workgroup
+}
 
 // thread part of a table index: bit e <- address bit pos[e]
 __device__ __forceinline__ uint32_t multi_jt(const MultiOp& op, uint64_t base) {
@@ -682,7 +701,7 @@ __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __r
 // shape of a fused QCMRF circuit): the general paths are compiled out.
 template <int R, bool INIT, int MODE>
 __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
-                                                   BitIns ins, RegPos rp,
+                                                   BitIns ins, RegPos rp, LanePos lp,
                                                    const MultiOp* __restrict__ ops,
                                                    const MultiSlot* __restrict__ slots, int nrounds,
                                                    const cplx* __restrict__ tables, int ntab,
@@ -699,8 +718,8 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
   if (gb + threadIdx.x >= nthreads) return;
   // address = (uniform 64-bit pointer: shard + block part + register offset) + 32-bit lane part
-  const uint64_t base_blk = ins_bits(gb, ins);                       // wave-uniform
-  const uint32_t base_thr = (uint32_t)ins_bits((uint64_t)threadIdx.x, ins);
+  const uint64_t base_blk = tile_base_blk(blockIdx.x, ins, lp);      // wave-uniform
+  const uint32_t base_thr = tile_base_thr(threadIdx.x, ins, lp);
   const uint64_t base = base_blk | base_thr;
   cplx* __restrict__ pblk = amp + base_blk;
   // register-bit offsets once, in SGPRs (otherwise every one of the 2^R loads re-reads its
@@ -881,7 +900,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair_x(cplx* __restrict__ amp, uint
 // one workgroup per shot, tiles in the order the last k_multi pass left them: thread t owns the
 // 2^R amplitudes base(t) | off(j); find the first (t, j) whose running |amp|^2 exceeds resid[s]
 template <int R>
-__global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict__ amp, BitIns ins, RegPos rp,
+__global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict__ amp, BitIns ins, RegPos rp, LanePos lp,
                                                          const uint64_t* __restrict__ blk,
                                                          const double* __restrict__ resid,
                                                          uint64_t* __restrict__ out, uint64_t shots) {
@@ -890,7 +909,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict_
   __shared__ unsigned long long lastnz;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint64_t s = blockIdx.x; s < shots; s += gridDim.x) {
-    const uint64_t base = ins_bits(blk[s] * QSV_TPB + threadIdx.x, ins);
+    const uint64_t base = tile_base_blk(blk[s], ins, lp) | tile_base_thr(threadIdx.x, ins, lp);
     const double r = resid[s];
     double p[1 << R];
     double mine = 0.0;

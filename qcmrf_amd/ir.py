@@ -67,7 +67,7 @@ def snap(m, tol=4e-16):
 
 class Op:
     __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
-                 "a", "b", "label")
+                 "a", "b", "label", "new_pass")
 
     def __init__(self, kind, target=None, ctrls=(), vals=(), qubits=(), mat=None, table=None, mats=None,
                  angle=0.0, mask=0, a=(), b=(), label=""):
@@ -79,6 +79,7 @@ class Op:
         self.mask = mask
         self.a, self.b = a, b
         self.label = label
+        self.new_pass = False        # planner hint: this gate opens a new multi-gate pass
 
     def support(self):
         """every logical qubit the op reads or writes"""

@@ -53,9 +53,11 @@ def _remap(op, lay):
 
 LANE_BITS = 6      # address bits 0..5 are the lane id of a wavefront load (1 KiB contiguous)
 MULTI_R = 5        # register targets per k_multi pass (libqsv option multi_r)
+DYN_LANES = 3      # lane bits 3..5 that libqsv lends to further targets of a pass (option dyn_lanes)
+STATIC_LOW = 3     # lane bits 0..2: never lent (one 128-byte line per lane group)
 
 
-def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True):
+def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn_lanes=DYN_LANES, want_heads=False):
     """layout[logical] = physical.
 
     auto, measured on MI355X (profiles/r01_multi_bits_W28.json): a k_multi pass streams at
@@ -66,7 +68,7 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True):
     g = n_shards.bit_length() - 1
     L = n_qubits - g
     if layout == "reference":
-        return list(range(n_qubits))
+        return (list(range(n_qubits)), []) if want_heads else list(range(n_qubits))
     if layout != "auto":
         raise ValueError("layout must be 'auto' or 'reference', not %r" % (layout,))
     dense_first = {}
@@ -94,33 +96,62 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True):
     quiet_u = [q for q in rest if q not in dense_first and (uniform >> q) & 1]
     quiet_z = [q for q in rest if q not in dense_first and not (uniform >> q) & 1]
     # Dense targets beyond what the register tile holds per pass ride on LANE bits: a gate whose
-    # target is address bit < 6 is a wave shuffle inside the same k_multi pass, so a pass reaches
-    # MULTI_R register targets plus up to 6 lane targets.  Targets are taken in first-use order:
-    # per pass MULTI_R go to register positions (>= 6), that pass's share of the lane quota to lane
-    # positions -- 15 cliques need 2 passes instead of 3, 19 cliques 3 instead of 4.
+    # target is carried by a lane bit is a wave shuffle inside the same k_multi pass.  Two ways:
+    #   static   the qubit sits on address bit 0..5 for the whole circuit (6 such targets in all);
+    #   borrowed libqsv lends lane bits 3..5 to up to DYN_LANES targets PER PASS (any bit 6..27; a wave
+    #            load is then 8 x 128-byte lines instead of 1 KiB), leaving 3 static ones on bits 0..2.
+    # Targets are dealt in first-use order: per pass the register (+ borrowed) quota goes to
+    # positions >= 6, then that pass's share of the static quota to lane positions.  The borrowed
+    # form is chosen when it saves a pass: 19 cliques (W = 34) 3 -> 2 passes.
     lane_t, reg_t = [], list(dense)
-    if lane_targets and len(dense) > MULTI_R and L >= 12:
-        n_pass = max(1, -(-(len(dense) - LANE_BITS) // MULTI_R))
-        n_lane_t = min(LANE_BITS, max(0, len(dense) - MULTI_R * n_pass))
-        reg_t, k = [], 0
-        for i in range(n_pass):
-            reg_t += dense[k:k + MULTI_R]
-            k += MULTI_R
-            share = n_lane_t // n_pass + (1 if i < n_lane_t % n_pass else 0)
+    nd = len(dense)
+    pass_heads = []          # first dense target of every pass after the first
+    if lane_targets and nd > MULTI_R and L >= 12:
+        n_pass_static = max(1, -(-(nd - LANE_BITS) // MULTI_R))
+        n_pass_dyn = max(1, -(-(nd - STATIC_LOW) // (MULTI_R + dyn_lanes))) if dyn_lanes else n_pass_static
+        if n_pass_dyn < n_pass_static:
+            per_pass, n_pass, quota = MULTI_R + dyn_lanes, n_pass_dyn, STATIC_LOW
+        else:
+            per_pass, n_pass, quota = MULTI_R, n_pass_static, LANE_BITS
+        # The FIRST pass of a circuit is the init-fused, write-only one: with no load latency to
+        # hide behind, a lane gate is exposed there (measured, scripts/dyn_lane_cost.py: +19 % for
+        # three), while a read+write pass takes six for +2 %.  So the first pass gets its register
+        # targets and only as many lane-borne ones as the later passes cannot hold.
+        n_lane_t = min(quota, max(0, nd - per_pass * n_pass))
+        first = nd if n_pass == 1 else max(MULTI_R, nd - ((n_pass - 1) * per_pass + quota))
+        first_big = min(first, per_pass)
+        first_lane = first - first_big
+        later_lane = n_lane_t - first_lane
+        big = [list(dense[:first_big])]
+        k = first_big
+        lane_t += dense[k:k + first_lane]
+        k += first_lane
+        for i in range(1, n_pass):
+            if k < nd:
+                pass_heads.append(dense[k])
+            big.append(list(dense[k:k + per_pass]))
+            k += per_pass
+            share = later_lane // (n_pass - 1) + (1 if i - 1 < later_lane % (n_pass - 1) else 0)
             lane_t += dense[k:k + share]
             k += share
-        reg_t += dense[k:]
-    n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - len(dense)), len(quiet_u))
-    order = quiet_u[:n_quiet_lane] + lane_t + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...
+        # Positions: the read+write passes take the low bits (measured at W = 34,
+        # scripts/placement_sweep.py: the same pass runs at 5.4 TB/s on bits 6..13 and 5.05 TB/s on
+        # 14..21), the write-only first pass -- indifferent to where its targets sit -- the block above
+        reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
+    n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - nd), len(quiet_u))
+    # static lane targets take the lowest bits: bits 3..5 stay free to be lent out
+    order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...
     lay = [0] * n_qubits
     for p, q in enumerate(order):
         lay[q] = p
     for p, q in enumerate(shard_q):
         lay[q] = L + p
+    if want_heads:
+        return lay, pass_heads
     return lay
 
 
-def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True):
+def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True, dyn_lanes=DYN_LANES):
     """ops on logical qubits (first op is ``init``) -> Plan with physical ops."""
     if n_shards < 1 or n_shards & (n_shards - 1):
         raise ValueError("number of shards must be a power of two")
@@ -128,7 +159,8 @@ def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True):
     L = n_qubits - g
     if L < 1:
         raise ValueError("%d qubits cannot be split into %d shards" % (n_qubits, n_shards))
-    lay = choose_layout(ops, n_qubits, n_shards, layout, lane_targets)
+    lay, heads = choose_layout(ops, n_qubits, n_shards, layout, lane_targets, dyn_lanes, want_heads=True)
+    heads = set(heads)
     P = Plan()
     P.n_qubits, P.n_shards = n_qubits, n_shards
     P.initial_layout = list(lay)
@@ -160,5 +192,10 @@ def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True):
                 P.n_exchanges += 1
                 lay[t], lay[victim] = lay[victim], lay[t]
         P.ops.append(_remap(op, lay))
+        # pass boundary chosen with the layout: the first gate on the first target of a later pass
+        hit = heads.intersection(op.dense_targets())
+        if hit:
+            P.ops[-1].new_pass = True
+            heads -= hit
     P.layout = list(lay)
     return P

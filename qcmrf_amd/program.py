@@ -34,6 +34,8 @@ def encode(ops):
 
     for r, op in zip(rec, ops):
         k = op.kind
+        if op.new_pass:
+            r["flags"] = _lib.OPF_NEW_PASS
         if k == "init":
             r["kind"] = _lib.OP_INIT_UNIFORM if op.mask else _lib.OP_INIT_ZERO
             r["mask"] = op.mask
