@@ -413,3 +413,89 @@ def test_random_circuit_w20_against_c_oracle(be, fusion):
         amp, meta = run_state(be, qc, fusion=fusion, engine_options=opts)
         assert np.abs(amp - ref.state).max() < 1e-12, (fusion, opts)
     be.run(qc, shots=0, engine_options={"zero_tracking": 0, "lane_targets": 1, "multi_r": 5})
+
+
+def _lane_program(W, regs, lanes, rx_like, seed, with_diag=False, init=True, hints=()):
+    """init + one multiplexed 2x2 per target (selects on two quiet high bits): the shape of a fused
+    QCMRF circuit, with as many distinct targets as one k_multi pass can be made to hold"""
+    from qcmrf_amd import ir
+    rs = np.random.RandomState(seed)
+
+    def mat():
+        if rx_like:
+            a = rs.rand() * 3
+            return np.array([[np.cos(a), -1j * np.sin(a)], [-1j * np.sin(a), np.cos(a)]])
+        q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
+        return q
+    sel = [W - 1, W - 2]
+    quiet = (1 << W) - 1
+    for q in regs + lanes:
+        quiet &= ~(1 << q)
+    ops = [ir.op_init(quiet)] if init else []
+    for t in regs + lanes:
+        ops.append(ir.op_mux(sel, t, np.array([mat() for _ in range(4)])))
+        if t in hints:
+            ops[-1].new_pass = True
+        if with_diag and t == regs[-1]:
+            ops.append(ir.op_diag([3, W - 3], np.exp(1j * rs.randn(4))))
+    return ops
+
+
+@pytest.mark.parametrize("rx_like", [True, False])
+def test_borrowed_lane_bits_and_lane_map(rx_like):
+    """k_multi lends lane bits 3..5 to targets anywhere below bit 28 (a wave load becomes 8 x 128 B)
+    and may remap lane bit 5 purely for the access pattern: both change only WHERE a lane's
+    amplitudes live, so every setting must reproduce the numpy engine to 1e-12 -- amplitudes and
+    the tile-order sampling that follows the last pass."""
+    from qcmrf_amd import _lib, program
+    from oracle.sharded_numpy import NumpyEngine
+    W = 17
+    cases = [
+        ([6, 7, 8, 9, 10], [11, 12, 13, 0, 1, 2], ()),          # 5 registers + 3 borrowed + 3 static lanes
+        ([6, 7, 8, 9, 10], [11, 4, 13, 2], ()),                 # a static lane target on bit 4 keeps its lane
+        ([9, 7, 12, 6, 14], [8, 13, 10], ()),                   # scattered registers, borrowed bits between them
+        ([6, 7, 8, 9, 10], [], ()),                             # lane_map = 1 pattern (lane bit 5 -> bit 11)
+        ([6, 7, 8, 9, 10], [0, 3, 4], ()),                      # ... with static lane gates beside it
+        ([6, 7, 8, 9, 10], [11, 12, 13, 14, 0], (14,)),         # planner hint: bit 14 opens the second pass
+    ]
+    with _lib.Engine(W) as eng:
+        for ci, (regs, lanes, hints) in enumerate(cases):
+            for with_diag in (False, True):
+                for init in (True, False):
+                    ops = _lane_program(W, regs, lanes, rx_like, 100 + ci, with_diag, init, hints)
+                    rec, data = program.encode(ops)
+                    ref = NumpyEngine(W)
+                    if not init:
+                        ref.init_uniform((1 << W) - 1)
+                    ref.exec(rec, data)
+                    want = ref.amplitudes()
+                    for dyn, lmap in ((3, 1), (0, 0), (1, 0), (2, 1), (3, 11 << 10 | 12 << 5)):
+                        eng.set_option("dyn_lanes", dyn)
+                        eng.set_option("lane_map", lmap)
+                        if not init:
+                            eng.init_uniform((1 << W) - 1)
+                        eng.reset_stats()
+                        eng.exec(rec, data)
+                        got = eng.amplitudes()
+                        assert np.abs(got - want).max() < 1e-12, (ci, with_diag, init, dyn, lmap)
+                        launches = sum(v["launches"] for v in eng.stats()["kinds"].values())
+                        if dyn == 3 and not with_diag and not hints and len(regs) + len(lanes) <= 11:
+                            assert launches == 1, (ci, launches)      # everything rode in ONE pass
+                        if hints and dyn == 3:
+                            assert launches == 2
+        # sampling straight from the tile sums of a pass that used borrowed lanes
+        ops = _lane_program(W, [6, 7, 8, 9, 10], [11, 12, 13, 0, 1, 2], rx_like, 7)
+        rec, data = program.encode(ops)
+        eng.set_option("dyn_lanes", 3)
+        eng.exec(rec, data)
+        p = np.abs(eng.amplitudes()) ** 2
+        shots = 200000
+        idx = eng.sample(shots, 11)
+        assert (eng.sample(shots, 11) == idx).all()
+        obs = np.bincount(idx.astype(np.int64), minlength=p.size)
+        assert obs[p == 0].sum() == 0
+        # 2^17 outcomes are too many for a per-outcome chi^2 at this shot count: bin by 64
+        pb, ob = p.reshape(-1, 64).sum(1), obs.reshape(-1, 64).sum(1)
+        keep = pb * shots > 5
+        chi = ((ob[keep] - pb[keep] * shots) ** 2 / (pb[keep] * shots)).sum() / (keep.sum() - 1)
+        assert 0.85 < chi < 1.15, chi
