@@ -49,7 +49,7 @@ typedef struct qsv_handle qsv_handle;
 /* kernel kinds, index into qsv_stats.per_kind[] */
 enum {
   QSV_K_INIT = 0, QSV_K_1Q, QSV_K_X, QSV_K_DIAG, QSV_K_MCPHASE, QSV_K_MUX, QSV_K_KQ,
-  QSV_K_PROB, QSV_K_SWAP, QSV_K_EXCHANGE, QSV_K_MULTI, QSV_K_MULTI_INIT, QSV_K_COUNT
+  QSV_K_PROB, QSV_K_SWAP, QSV_K_EXCHANGE, QSV_K_MULTI, QSV_K_MULTI_INIT, QSV_K_INIT_PROD, QSV_K_COUNT
 };
 
 typedef struct {

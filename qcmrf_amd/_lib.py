@@ -18,7 +18,7 @@ MAX_CTRL = 16
 MAX_KQ = 5
 UNIQUE_ID_BYTES = 128
 
-K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "exchange", "multi", "multi_init"]
+K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "exchange", "multi", "multi_init", "init_prod"]
 K_COUNT = len(K_NAMES)
 
 OP_INIT_ZERO, OP_INIT_UNIFORM, OP_1Q, OP_MCX, OP_DIAG, OP_MCPHASE, OP_MUX, OP_KQ, OP_SWAP = range(9)

@@ -91,6 +91,8 @@ class QsvBackend:
 
     fusion      0 gate by gate | 1 + init/diagonal fusion | 2 + multiplexer fusion |
                 3 + dense <=5-qubit windows with structure recovery (default)
+    fold_fresh  (fusion 3) gates whose target nothing has touched yet become factors of the
+                initial product state, written in the same pass as the state itself (default on)
     layout      'auto' (exchange-free where possible) | 'reference' (qubit q on index bit q)
     devices     HIP device id per shard owned by this process (repeat an id for virtual shards)
     method      'statevector' (default: all measurements deferred, one evolution, W qubits) |
@@ -103,7 +105,7 @@ class QsvBackend:
     def __init__(self, name="qasm_simulator", **options):
         self._name = name
         self.options = {"fusion": 3, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
-                        "profile": False, "engine_options": None, "method": "statevector"}
+                        "profile": False, "engine_options": None, "method": "statevector", "fold_fresh": True}
         self.options.update(options)
         self._engine = None
         self._engine_key = None
@@ -188,7 +190,7 @@ class QsvBackend:
         t0 = time.perf_counter()
         comm = opts["comm"] or SingleProcess()
         n_shards = comm.world if comm.world > 1 else len(opts["devices"])
-        ing, pl = self.compile(circuit, n_shards, **{k: opts[k] for k in ("fusion", "layout", "engine_options")})
+        ing, pl = self.compile(circuit, n_shards, **{k: opts[k] for k in ("fusion", "layout", "engine_options", "fold_fresh")})
         rec, data = program.encode(pl.ops)
         return ing, pl, rec, data, n_shards, time.perf_counter() - t0
 
@@ -197,7 +199,7 @@ class QsvBackend:
         opts = dict(self.options)
         opts.update(options)
         ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1)
-        ops = passes.optimise(ing.ops, level=opts["fusion"])
+        ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)))
         if ing.global_phase and opts.get("apply_global_phase", True):
             from . import ir
             ph = np.exp(1j * ing.global_phase)

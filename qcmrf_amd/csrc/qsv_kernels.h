@@ -792,6 +792,87 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_init_prod<R>: the initial product state times a list of diagonal factors, written once.
+//     amp[i] = ((i & nonmask) == 0 ? val : 0) * prod_k table_k[gather_k(i)]
+// This is what an `init` followed only by diagonal ops is (the shape a circuit takes when every
+// gate on a fresh qubit has been folded into the initial state, passes.fold_fresh): no reads, one
+// 16 B write per amplitude however many factors there are.  Each thread owns 2^R amplitudes (same
+// tile shape as k_multi, so the per-tile |amp|^2 sums feed the same tile-order sampling); factors
+// that do not touch a register bit are multiplied once per thread into a scalar, the others per
+// amplitude.  Roofline: HBM write, 16 B / amplitude.
+// ---------------------------------------------------------------------------------------
+struct ProdFactor {
+  int nlist;                      // table index bit e <- address bit pos[e] (pos[e] < 0: a register bit)
+  int tab;                        // table offset in LDS, complex128 units
+  int pos[QSV_MULTI_MAXLIST];
+  int regw[QSV_MULTI_MAXR];       // table-index weight of register bit c
+};
+template <int R>
+__global__ __launch_bounds__(QSV_TPB) void k_init_prod(cplx* __restrict__ amp, uint64_t nthreads, BitIns ins, RegPos rp,
+                                                       LanePos lp, const ProdFactor* __restrict__ fac, int nuni, int nvar,
+                                                       const cplx* __restrict__ tables, int ntab, uint64_t nonmask,
+                                                       double initval, double* __restrict__ tile_sums) {
+  extern __shared__ double4 lds_raw[];
+  cplx* lt = reinterpret_cast<cplx*>(lds_raw);
+  for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = tables[i];
+  __syncthreads();
+  const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
+  if (gb + threadIdx.x >= nthreads) return;
+  const uint64_t base_blk = tile_base_blk(blockIdx.x, ins, lp);
+  const uint32_t base_thr = tile_base_thr(threadIdx.x, ins, lp);
+  const uint64_t base = base_blk | base_thr;
+  cplx* __restrict__ pblk = amp + base_blk;
+  uint64_t ob[R > 0 ? R : 1];
+#pragma unroll
+  for (int c = 0; c < R; ++c) ob[c] = 1ull << rp.pos[c];
+  // factors without a register bit: one scalar per thread
+  cplx f = make_double2(((base & nonmask) == 0) ? initval : 0.0, 0.0);
+  for (int k = 0; k < nuni; ++k) {
+    const ProdFactor& pf = fac[k];
+    uint32_t jt = 0;
+    for (int e = 0; e < pf.nlist; ++e) jt |= (uint32_t)((base >> pf.pos[e]) & 1ull) << e;
+    f = cmul(f, lt[pf.tab + jt]);
+  }
+  cplx a[1 << R];
+#pragma unroll
+  for (int j = 0; j < (1 << R); ++j) {
+    uint64_t off = 0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
+    a[j] = ((off & nonmask) == 0) ? f : make_double2(0.0, 0.0);
+  }
+  for (int k = nuni; k < nuni + nvar; ++k) {
+    const ProdFactor& pf = fac[k];
+    uint32_t jt = 0;
+    for (int e = 0; e < pf.nlist; ++e) if (pf.pos[e] >= 0) jt |= (uint32_t)((base >> pf.pos[e]) & 1ull) << e;
+    const cplx* tp = lt + pf.tab + jt;
+#pragma unroll
+    for (int j = 0; j < (1 << R); ++j) {
+      int jr = 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += pf.regw[c];
+      a[j] = cmul(a[j], tp[jr]);
+    }
+  }
+  double psum = 0.0;
+#pragma unroll
+  for (int j = 0; j < (1 << R); ++j) {
+    uint64_t off = 0;
+#pragma unroll
+    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
+    (pblk + off)[base_thr] = a[j];
+    psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
+  }
+  if (tile_sums) {
+    __shared__ double wpart[QSV_TPB / 64];
+    psum = wave_sum(psum);
+    if ((threadIdx.x & 63) == 0) wpart[threadIdx.x >> 6] = psum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
+  }
+}
+
 // zero tracking epilogue: amplitudes with any bit of zmask set were never written; make them 0
 __global__ __launch_bounds__(QSV_TPB) void k_fill_zero(cplx* __restrict__ amp, uint64_t n, uint64_t zmask) {
   const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;

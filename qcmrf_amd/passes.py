@@ -590,6 +590,114 @@ def fuse_dense(ops, kmax=5):
 
 
 # --------------------------------------------------------------------------------------------
+# pass 4: gates on fresh qubits become factors of the initial product state
+# --------------------------------------------------------------------------------------------
+def _as_mux(op):
+    """(selects, target, mats[2^k,2,2]) of a 2x2-type op, controls spelled out as table entries"""
+    if op.kind == "mux":
+        return tuple(op.ctrls), op.target, op.mats
+    if op.kind in ("u", "x"):
+        m = op.mat if op.kind == "u" else _X2
+        k = len(op.ctrls)
+        mats = np.tile(np.eye(2, dtype=np.complex128), (1 << k, 1, 1))
+        hit = sum(int(v) << e for e, v in enumerate(op.vals))
+        mats[hit] = m
+        return tuple(op.ctrls), op.target, mats
+    return None
+
+
+def _as_diag(op):
+    if op.kind == "diag":
+        return tuple(op.qubits), op.table
+    if op.kind == "mcphase":
+        k = len(op.qubits)
+        t = np.ones(1 << k, dtype=np.complex128)
+        t[sum(int(v) << e for e, v in enumerate(op.vals))] = np.exp(1j * op.angle)
+        return tuple(op.qubits), t
+    return None
+
+
+def _slice_zero(qubits, table, populated, ent=1):
+    """drop every qubit outside ``populated`` from a table index: such a qubit is known |0>, so
+    only its 0-slice is ever read.  ``table`` has 2^k entries of ``ent`` values each."""
+    qubits = list(qubits)
+    t = np.asarray(table).reshape((2,) * len(qubits) + (ent,)) if qubits else np.asarray(table).reshape(1, ent)
+    # numpy axis a <-> qubits[k-1-a] (index bit e is qubit e, little-endian)
+    for e in range(len(qubits) - 1, -1, -1):
+        if not (populated >> qubits[e]) & 1:
+            t = np.take(t, 0, axis=len(qubits) - 1 - e)
+            del qubits[e]
+    return tuple(qubits), t.reshape(-1, ent)
+
+
+def fold_fresh(ops):
+    """[init(mask)] + ops  ->  [init(mask')] + diagonal factors + the ops that could not fold.
+
+    The state right after ``init`` is a product state known in closed form: amplitude ``val`` on
+    every index whose bits outside ``mask`` are 0.  A 2x2-type gate (u, x, mux; any controls)
+    whose TARGET nothing has touched yet does not need a sweep: applied to |0> it writes column 0
+    of its matrix, amp'(.., t=b, ..) = M_sel[b,0] amp(.., t=0, ..); applied to an untouched |+> it
+    writes the row sums.  Either way the result is again "``val`` times a table looked up from the
+    index", i.e. an ``init`` over mask + {t} followed by a DIAGONAL on (selects, t) -- which libqsv
+    evaluates while it writes the initial state, at no HBM traffic of its own.  Diagonal gates
+    multiply into the same product.  Selects on qubits still |0> are sliced away on the spot, so
+    a factor never depends on an unpopulated bit.
+
+    Exact and structural (which qubits an op touches, the |0..0> start) -- the rule any simulator
+    may apply to a gate on a freshly allocated qubit; for a QCMRF circuit every clique block ends up
+    here, because each ancilla is touched by exactly one fused multiplexer (QCMRF.py:231-236).
+    Folding stops, per qubit, at the first op that cannot fold: everything after it on those
+    qubits is emitted unchanged, in order."""
+    if not ops or ops[0].kind != "init":
+        return list(ops)
+    populated = ops[0].mask          # bits whose |1> half carries amplitude
+    plus = ops[0].mask               # populated AND still exactly |+>, untouched by any factor
+    blocked = set()                  # qubits an emitted (unfolded) op has touched
+    factors, emitted = [], []
+    scalar = 1.0 + 0.0j
+    for op in ops[1:]:
+        sup = set(op.support())
+        done = False
+        if not (sup & blocked):
+            dg = _as_diag(op)
+            mx = _as_mux(op) if dg is None else None
+            if dg is not None:
+                q, t = _slice_zero(dg[0], dg[1], populated)
+                if q:
+                    factors.append(ir.op_diag(q, t.ravel()))
+                    for x in q:
+                        plus &= ~(1 << x)
+                else:
+                    scalar *= t.ravel()[0]
+                done = True
+            elif mx is not None:
+                sel, tg, mats = mx
+                in_pop = (populated >> tg) & 1
+                if not in_pop or (plus >> tg) & 1:
+                    sq, st = _slice_zero(sel, np.asarray(mats).reshape(-1, 4), populated, ent=4)
+                    st = st.reshape(-1, 2, 2)
+                    col = st[:, :, 0] * np.sqrt(2.0) if not in_pop else st[:, :, 0] + st[:, :, 1]
+                    # table index: bits 0..k-1 the surviving selects, bit k the target
+                    tab = np.concatenate([col[:, 0], col[:, 1]])
+                    factors.append(ir.op_diag(tuple(sq) + (tg,), tab))
+                    populated |= 1 << tg
+                    for x in tuple(sq) + (tg,):
+                        plus &= ~(1 << x)
+                    done = True
+        if not done:
+            emitted.append(op)
+            blocked |= sup
+            for x in sup:
+                plus &= ~(1 << x)
+    if abs(scalar - 1.0) > 1e-15:
+        if factors:
+            factors[0] = ir.op_diag(factors[0].qubits, factors[0].table * scalar)
+        else:
+            factors.append(ir.op_diag([0], [scalar, scalar]))
+    return [ir.op_init(populated)] + factors + emitted
+
+
+# --------------------------------------------------------------------------------------------
 def _fuse_body(ops, level, kmax, smax, lowered=False):
     head, body = ops[:1], ops[1:]
     if lowered and level >= 3:
@@ -603,10 +711,16 @@ def _fuse_body(ops, level, kmax, smax, lowered=False):
     return head + body
 
 
-def optimise(ops, level=3, kmax=10, smax=8):
+def optimise(ops, level=3, kmax=10, smax=8, fresh=True):
     """level 0: gate by gate as ingested (|0..0> init prepended).
     level 1: + init folding + diagonal (monomial) fusion.   level 2: + multiplexer fusion.
-    level 3: + dense <= 5-qubit windows with structure recovery (for basis-gate circuits)."""
+    level 3: + dense <= 5-qubit windows with structure recovery (for basis-gate circuits)
+             + (``fresh``) gates on untouched qubits folded into the initial product state."""
+    out = _optimise(ops, level, kmax, smax)
+    return fold_fresh(out) if (fresh and level >= 3) else out
+
+
+def _optimise(ops, level, kmax, smax):
     if level <= 0:
         return [ir.op_init(0)] + list(ops)
     lead, rest = split_leading(ops)

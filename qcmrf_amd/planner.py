@@ -138,6 +138,21 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
         # scripts/placement_sweep.py: the same pass runs at 5.4 TB/s on bits 6..13 and 5.05 TB/s on
         # 14..21), the write-only first pass -- indifferent to where its targets sit -- the block above
         reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
+    if not dense and L >= 14:
+        # nothing left but the initial product state and its diagonal factors (passes.fold_fresh):
+        # libqsv's generator keeps bits 6..10 in registers and multiplies a factor per AMPLITUDE
+        # if it touches one of them, per THREAD otherwise -- give those bits the qubits the fewest
+        # factors touch (for a QCMRF circuit: ancillas, one factor each)
+        uses = {q: 0 for q in quiet_u}
+        for op in ops:
+            if op.kind in ("diag", "mcphase"):
+                for q in op.qubits:
+                    if q in uses:
+                        uses[q] += 1
+        regq = sorted(sorted(quiet_u, key=lambda q: (uses[q], -q))[:MULTI_R])
+        others = [q for q in quiet_u if q not in regq]
+        if len(others) >= LANE_BITS and len(regq) == MULTI_R:
+            quiet_u = others[:LANE_BITS] + regq + others[LANE_BITS:]
     n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - nd), len(quiet_u))
     # static lane targets take the lowest bits: bits 3..5 stay free to be lent out
     order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...

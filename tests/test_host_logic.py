@@ -246,12 +246,15 @@ def test_lowered_qcmrf_is_reassembled_into_one_multiplexer_per_clique():
     th = random_theta(cf.model_shape(C)[3])
     t = transpile(QCMRF(C, th))
     be = QsvBackend()
-    ing, pl = be.compile(t)
+    ing, pl = be.compile(t, fold_fresh=False)
     kinds = [o.kind for o in pl.ops]
     assert len(t.data) > 2000 and kinds[0] == "init"
     assert kinds.count("mux") == 7 and kinds.count("kq") == 0 and set(kinds) <= {"init", "mux", "diag"}
     n = cf.model_shape(C)[0]
-    assert bin(be.compile(t, layout="reference")[1].ops[0].mask).count("1") == n     # variables folded into init
+    assert bin(be.compile(t, layout="reference", fold_fresh=False)[1].ops[0].mask).count("1") == n     # variables folded into init
+    # default: every multiplexer acts on a fresh ancilla and becomes a factor of the initial state
+    ing, pl = be.compile(t)
+    assert [o.kind for o in pl.ops].count("mux") == 0 and bin(pl.ops[0].mask).count("1") == n + 7
     amp, _, _, _ = run_numpy(t)
     assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-11
 

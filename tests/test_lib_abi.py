@@ -38,7 +38,7 @@ def test_header_symbols_all_exported_and_bound(lib_path):
 def test_op_record_layout_matches_header():
     from qcmrf_amd import _lib
     assert ctypes.sizeof(_lib.QsvOp) == 4 * 4 + 2 * 16 * 4 + 8 + 8 + 8 == _lib.OP_DTYPE.itemsize
-    assert _lib.K_COUNT == 12 and ctypes.sizeof(_lib.Stats) == 12 * 24 + 8 + 8 + 8
+    assert _lib.K_COUNT == 13 and ctypes.sizeof(_lib.Stats) == 13 * 24 + 8 + 8 + 8
 
 
 def test_code_object_is_gfx950_only(lib_path):

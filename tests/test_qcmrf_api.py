@@ -105,8 +105,10 @@ def test_backend_surface_without_gpu():
     with pytest.raises(ValueError):
         Aer.get_backend("ibm_torino")
     C = [[0, 1], [1, 2]]
-    ing, pl = b.compile(QCMRF(C, [-0.2] * 8))
+    ing, pl = b.compile(QCMRF(C, [-0.2] * 8), fold_fresh=False)
     assert [o.kind for o in pl.ops] == ["init", "mux", "mux"] and sorted(pl.layout) == list(range(6))
+    ing, pl = b.compile(QCMRF(C, [-0.2] * 8))
+    assert [o.kind for o in pl.ops] == ["init", "diag", "diag"] and bin(pl.ops[0].mask).count("1") == 5
 
 
 def test_eval_module_reproduces_the_table_from_the_committed_aer_counts(tmp_path, aer_counts):
