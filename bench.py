@@ -282,18 +282,29 @@ def main():
     def leg(name, n, circuit=None, **opts):
         comm.barrier()
         t0 = time.perf_counter()
+        agg = {}
         for i in range(n):
-            r = backend.run(circuit or qc, shots=args.shots, seed_simulator=77 + i, **opts).result()
+            r = backend.run(circuit or qc, shots=args.shots, seed_simulator=77 + i, profile=True, **opts).result()
+            for k, v in r.metadata(0)["stats"]["kinds"].items():
+                a = agg.setdefault(k, {"launches": 0, "bytes": 0.0, "ms": 0.0})
+                for f in a:
+                    a[f] += v[f]
         backend.last_engine.sync()
         comm.barrier()
         dt = max(comm.allgather(time.perf_counter() - t0))
         m = r.metadata(0)
         variants[name] = {"shots_per_s": args.shots * n / dt, "ms_per_step": dt / n * 1e3,
-                          "device_ops": m["n_device_ops"], "evolve_ms": m["time_evolve"] * 1e3}
+                          "device_ops": m["n_device_ops"], "evolve_ms": m["time_evolve"] * 1e3,
+                          "kernels": {k: {"launches_per_step": a["launches"] / n, "avg_ms": a["ms"] / a["launches"],
+                                          "GBps": a["bytes"] / a["ms"] / 1e6 if a["ms"] > 0 else None,
+                                          "frac_of_8TBps": a["bytes"] / a["ms"] / 1e6 / HBM_PEAK_GBPS if a["ms"] > 0 else None}
+                                      for k, a in agg.items()}}
 
     if not args.no_variants:
         n = max(2, args.steps // 2)
-        leg("zero_tracking (opt-in: skips the provably-zero part of the vector)", n, engine_options={"zero_tracking": 1})
+        leg("full-width gate sweeps (fold_fresh off: init-fused pass + read/write k_multi passes)", n, fold_fresh=False)
+        leg("full-width gate sweeps + zero tracking (opt-in: skips the provably-zero part of the vector)", n,
+            fold_fresh=False, engine_options={"zero_tracking": 1})
         if world == 1 or args.with_exchange:
             # N > 1: the unfused stream needs shard-bit exchanges (RCCL); opt-in there, because a
             # first-ever RCCL bring-up must not be able to take the main measurement down with it
@@ -301,7 +312,7 @@ def main():
         if world == 1:
             from qcmrf_amd.transpile import transpile
             leg("lowered to {cx,id,rz,sx,x} as run_experiment.py:52 (stand-in transpiler, not timed) -> fusion 3",
-                2, circuit=transpile(qc), fusion=args.fusion)
+                2, circuit=transpile(qc), fusion=args.fusion, engine_options={"zero_tracking": 0})
         backend.run(qc, shots=16, engine_options={"zero_tracking": 0})
 
     # N = 1: the other single-GPU configs of BASELINE.json, same step definition (not part of `value`)

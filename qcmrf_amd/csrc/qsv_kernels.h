@@ -799,8 +799,10 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
 // gate on a fresh qubit has been folded into the initial state, passes.fold_fresh): no reads, one
 // 16 B write per amplitude however many factors there are.  Each thread owns 2^R amplitudes (same
 // tile shape as k_multi, so the per-tile |amp|^2 sums feed the same tile-order sampling); factors
-// that do not touch a register bit are multiplied once per thread into a scalar, the others per
-// amplitude.  Roofline: HBM write, 16 B / amplitude.
+// that do not touch a register bit are multiplied once per thread into a scalar; factors that
+// touch exactly one register bit are expanded bit by bit (1 -> 2 -> 4 ... 2^R values: 2^(R+1) - 2
+// complex multiplies for the whole tile instead of 2^R per factor); only factors on two or more
+// register bits cost one multiply per amplitude.  Roofline: HBM write, 16 B / amplitude.
 // ---------------------------------------------------------------------------------------
 struct ProdFactor {
   int nlist;                      // table index bit e <- address bit pos[e] (pos[e] < 0: a register bit)
@@ -808,9 +810,12 @@ struct ProdFactor {
   int pos[QSV_MULTI_MAXLIST];
   int regw[QSV_MULTI_MAXR];       // table-index weight of register bit c
 };
+// factor list order: nuni thread-uniform ones, then nsingle[c] factors on register bit c only
+// (c = 0..R-1), then nmulti factors on several register bits
+struct ProdCounts { int nuni; int nsingle[QSV_MULTI_MAXR]; int nmulti; };
 template <int R>
 __global__ __launch_bounds__(QSV_TPB) void k_init_prod(cplx* __restrict__ amp, uint64_t nthreads, BitIns ins, RegPos rp,
-                                                       LanePos lp, const ProdFactor* __restrict__ fac, int nuni, int nvar,
+                                                       LanePos lp, const ProdFactor* __restrict__ fac, ProdCounts cnt,
                                                        const cplx* __restrict__ tables, int ntab, uint64_t nonmask,
                                                        double initval, double* __restrict__ tile_sums) {
   extern __shared__ double4 lds_raw[];
@@ -828,21 +833,35 @@ __global__ __launch_bounds__(QSV_TPB) void k_init_prod(cplx* __restrict__ amp, u
   for (int c = 0; c < R; ++c) ob[c] = 1ull << rp.pos[c];
   // factors without a register bit: one scalar per thread
   cplx f = make_double2(((base & nonmask) == 0) ? initval : 0.0, 0.0);
-  for (int k = 0; k < nuni; ++k) {
+  int k0 = 0;
+  for (int k = 0; k < cnt.nuni; ++k) {
     const ProdFactor& pf = fac[k];
     uint32_t jt = 0;
     for (int e = 0; e < pf.nlist; ++e) jt |= (uint32_t)((base >> pf.pos[e]) & 1ull) << e;
     f = cmul(f, lt[pf.tab + jt]);
   }
+  k0 = cnt.nuni;
   cplx a[1 << R];
+  a[0] = f;
 #pragma unroll
-  for (int j = 0; j < (1 << R); ++j) {
-    uint64_t off = 0;
+  for (int c = 0; c < R; ++c) {
+    // both values of register bit c: product of the factors that see this bit and no other
+    cplx t0 = make_double2(1.0, 0.0), t1 = make_double2((ob[c] & nonmask) ? 0.0 : 1.0, 0.0);
+    for (int k = k0; k < k0 + cnt.nsingle[c]; ++k) {
+      const ProdFactor& pf = fac[k];
+      uint32_t jt = 0;
+      for (int e = 0; e < pf.nlist; ++e) if (pf.pos[e] >= 0) jt |= (uint32_t)((base >> pf.pos[e]) & 1ull) << e;
+      t0 = cmul(t0, lt[pf.tab + jt]);
+      t1 = cmul(t1, lt[pf.tab + jt + pf.regw[c]]);
+    }
+    k0 += cnt.nsingle[c];
 #pragma unroll
-    for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-    a[j] = ((off & nonmask) == 0) ? f : make_double2(0.0, 0.0);
+    for (int j = 0; j < (1 << c); ++j) {
+      a[j | (1 << c)] = cmul(a[j], t1);
+      a[j] = cmul(a[j], t0);
+    }
   }
-  for (int k = nuni; k < nuni + nvar; ++k) {
+  for (int k = k0; k < k0 + cnt.nmulti; ++k) {
     const ProdFactor& pf = fac[k];
     uint32_t jt = 0;
     for (int e = 0; e < pf.nlist; ++e) if (pf.pos[e] >= 0) jt |= (uint32_t)((base >> pf.pos[e]) & 1ull) << e;

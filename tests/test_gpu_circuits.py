@@ -499,3 +499,58 @@ def test_borrowed_lane_bits_and_lane_map(rx_like):
         keep = pb * shots > 5
         chi = ((ob[keep] - pb[keep] * shots) ** 2 / (pb[keep] * shots)).sum() / (keep.sum() - 1)
         assert 0.85 < chi < 1.15, chi
+
+
+def test_init_product_generator_against_numpy_engine():
+    """init + diagonal factors only -> k_init_prod (one write-only pass).  Factors on no / one /
+    several of the generator's register bits (6..10), unpopulated bits in and outside the tile,
+    sampling from its tile sums; same program through the ordinary k_multi path (init_prod = 0)."""
+    from qcmrf_amd import _lib, ir, program
+    from oracle.sharded_numpy import NumpyEngine
+    W = 16
+    rs = np.random.RandomState(5)
+    with _lib.Engine(W) as eng:
+        for case in range(6):
+            mask = (1 << W) - 1
+            for q in rs.choice(W, size=case % 4, replace=False):      # some qubits stay |0>
+                mask &= ~(1 << int(q))
+            ops = [ir.op_init(mask)]
+            for _ in range(12):
+                k = int(rs.randint(1, 5))
+                qs = [int(q) for q in rs.choice(W, size=k, replace=False)]
+                ops.append(ir.op_diag(qs, rs.randn(2 ** k) + 1j * rs.randn(2 ** k)))
+            ops.append(ir.op_diag([6, 7, 8, 9, 10], np.exp(1j * rs.randn(32))))      # all register bits at once
+            rec, data = program.encode(ops)
+            ref = NumpyEngine(W)
+            ref.exec(rec, data)
+            want = ref.amplitudes()
+            scale = np.abs(want).max()
+            for ip in (1, 0):
+                eng.set_option("init_prod", ip)
+                eng.reset_stats()
+                eng.exec(rec, data)
+                kinds = {k: v["launches"] for k, v in eng.stats()["kinds"].items()}
+                assert ("init_prod" in kinds) == bool(ip), kinds
+                if ip:
+                    assert kinds == {"init_prod": 1}
+                assert np.abs(eng.amplitudes() - want).max() < 1e-12 * max(1.0, scale), (case, ip)
+        eng.set_option("init_prod", 1)
+        # a normalised product state: sample from the generator's tile sums
+        ops = [ir.op_init((1 << W) - 1 - (1 << 3))]          # bit 7 populated by the folded-gate-like factor below
+        for q in range(0, W - 1, 2):
+            th = rs.rand(4) * 3
+            ops.append(ir.op_diag([q, q + 1], np.exp(1j * th)))
+        a = rs.rand() * 3
+        ops.append(ir.op_diag([0, 7], np.sqrt(2.0) * np.array([np.cos(a), np.cos(a / 2), -1j * np.sin(a), -1j * np.sin(a / 2)])))
+        rec, data = program.encode(ops)
+        eng.exec(rec, data)
+        p = np.abs(eng.amplitudes()) ** 2
+        assert abs(p.sum() - 1.0) < 1e-12 and abs(eng.norm() - 1.0) < 1e-12
+        shots = 100000
+        idx = eng.sample(shots, 3)
+        obs = np.bincount(idx.astype(np.int64), minlength=p.size)
+        assert obs[p == 0].sum() == 0
+        pb, ob = p.reshape(-1, 64).sum(1), obs.reshape(-1, 64).sum(1)
+        keep = pb * shots > 5
+        chi = ((ob[keep] - pb[keep] * shots) ** 2 / (pb[keep] * shots)).sum() / (keep.sum() - 1)
+        assert 0.8 < chi < 1.2, chi
