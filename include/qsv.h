@@ -151,7 +151,8 @@ int qsv_probabilities_cond(qsv_handle* h, const int* qubits, int k,
 int qsv_norm(qsv_handle* h, double* out);
 
 /* draw `shots` basis states from |amp|^2 over this process's shards (normalised by their
- * mass); out_bits[s] bit j = value of qubit meas_qubits[j] (n_meas <= 64).
+ * mass); out_bits[s] bit j = value of qubit meas_qubits[j] (n_meas <= 64; an entry of -1 leaves
+ * bit j at 0: a classical bit no measurement writes).
  * meas_qubits == NULL: out_bits[s] = the full basis index. */
 int qsv_sample(qsv_handle* h, uint64_t shots, uint64_t seed, const int* meas_qubits,
                int n_meas, uint64_t* out_bits);

@@ -168,7 +168,8 @@ class NumpyEngine:
             return pick
         out = np.zeros(shots, dtype=np.uint64)
         for b, q in enumerate(meas_qubits):
-            out |= ((pick >> np.uint64(q)) & np.uint64(1)) << np.uint64(b)
+            if q >= 0:                                     # -1: an output bit nothing is measured into
+                out |= ((pick >> np.uint64(q)) & np.uint64(1)) << np.uint64(b)
         return out
 
     # ---- the rest of the qcmrf_amd._lib.Engine surface the backend touches

@@ -248,7 +248,16 @@ class QsvBackend:
         t2 = time.perf_counter()
 
         clist = sorted(ing.measure)
-        meas_phys = [pl.layout[ing.measure[c]] for c in clist]
+        # output bit c <- the qubit measured into classical bit c (-1: never written, stays 0), so
+        # the sampled words come back already laid out as the classical register
+        if clist and clist[-1] < 64:
+            meas_phys = [-1] * (clist[-1] + 1)
+            for c in clist:
+                meas_phys[c] = pl.layout[ing.measure[c]]
+            direct = True
+        else:
+            meas_phys = [pl.layout[ing.measure[c]] for c in clist]
+            direct = False
         counts = {}
         if clist and shots > 0:
             if comm.world > 1:
@@ -258,9 +267,12 @@ class QsvBackend:
                 bits = np.concatenate(comm.allgather(mine))
             else:
                 bits = eng.sample(shots, seed, meas_phys)
-            vals = np.zeros(bits.shape, dtype=np.uint64)
-            for j, c in enumerate(clist):
-                vals |= ((bits >> np.uint64(j)) & np.uint64(1)) << np.uint64(c)
+            if direct:
+                vals = bits
+            else:
+                vals = np.zeros(bits.shape, dtype=np.uint64)
+                for j, c in enumerate(clist):
+                    vals |= ((bits >> np.uint64(j)) & np.uint64(1)) << np.uint64(c)
             uv, uc = np.unique(vals, return_counts=True)
             counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
         elif shots > 0:

@@ -115,6 +115,10 @@ struct Shard {
   // sums left behind by the last k_multi pass of a program, one per workgroup tile (no read pass)
   double* d_tsums = nullptr;
   size_t tsums_cap = 0;
+  double* d_super = nullptr;     // one sum per QSV_SUPER tiles (device) ...
+  double* h_tsums = nullptr;     // ... and their pinned host copy, valid until the state changes
+  size_t h_tsums_cap = 0;
+  bool h_tsums_valid = false;
   bool tile_valid = false, tile_fresh = false;
   int tile_R = 0;
   RegPos tile_rp;
@@ -224,7 +228,7 @@ static int launch(qsv_handle* h, Shard& s, int kind, double bytes, F&& f) {
   }
   f();
   HIPCHK(hipGetLastError());
-  if (kind != QSV_K_PROB) { s.sums_valid = false; s.tile_valid = false; }   // any state change drops cached sums
+  if (kind != QSV_K_PROB) { s.sums_valid = false; s.tile_valid = false; s.h_tsums_valid = false; }   // any state change drops cached sums
   if (h->profiling) {
     HIPCHK(hipEventRecord(p.e1, s.stream));
     s.pending.push_back(p);
@@ -313,6 +317,8 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     for (int b = 0; b < 2; ++b) if (s.xbuf[b]) hipFree(s.xbuf[b]);
     if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
     if (s.d_tsums) hipFree(s.d_tsums);
+    if (s.h_tsums) hipHostFree(s.h_tsums);
+    if (s.d_super) hipFree(s.d_super);
     if (s.stream) hipStreamDestroy(s.stream);
   }
   if (h->t0) hipEventDestroy(h->t0);

@@ -391,6 +391,72 @@ __global__ __launch_bounds__(64) void k_locate(const cplx* __restrict__ amp, uin
   }
 }
 
+// Two-level walk over the per-tile sums a program's last pass left behind (2^21 of them for a
+// 34-qubit shard): the host only ever sees one sum per QSV_SUPER tiles.
+#define QSV_SUPER 1024
+// super[b] = sum of tile sums [b*QSV_SUPER, (b+1)*QSV_SUPER) in a fixed order (deterministic)
+__global__ __launch_bounds__(QSV_TPB) void k_supersum(const double* __restrict__ tsum, uint64_t ntiles,
+                                                      double* __restrict__ super, uint64_t nsuper) {
+  __shared__ double part[QSV_TPB / 64];
+  for (uint64_t b = blockIdx.x; b < nsuper; b += gridDim.x) {
+    const uint64_t lo = b * QSV_SUPER;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < QSV_SUPER / QSV_TPB; ++k) {
+      const uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
+      if (i < ntiles) s += tsum[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) super[b] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+  }
+}
+// one wave per shot: blk[s] holds a super-block index and resid[s] the mass to walk into it;
+// replace them by the tile index inside that super block and the mass left over for the tile
+__global__ __launch_bounds__(64) void k_locate_super(const double* __restrict__ tsum, uint64_t ntiles,
+                                                     uint64_t* __restrict__ blk, double* __restrict__ resid,
+                                                     uint64_t shots) {
+  const int lane = threadIdx.x;
+  for (uint64_t s = blockIdx.x; s < shots; s += gridDim.x) {
+    const uint64_t lo = blk[s] * QSV_SUPER;
+    const double r = resid[s];
+    double run = 0.0, before_found = 0.0, before_last = 0.0;
+    uint64_t found = ~0ull, last_nz = lo;
+    for (int row = 0; row < QSV_SUPER / 64 && found == ~0ull; ++row) {
+      const uint64_t i = lo + (uint64_t)row * 64 + lane;
+      const double p = (i < ntiles) ? tsum[i] : 0.0;
+      double inc = p;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      const unsigned long long hit = __ballot(p > 0.0 && run + inc > r);
+      const unsigned long long nz = __ballot(p > 0.0);
+      if (hit) {
+        const int l = __builtin_ctzll(hit);
+        found = lo + (uint64_t)row * 64 + (uint64_t)l;
+        before_found = run + __shfl(inc - p, l, 64);
+      }
+      if (nz) {
+        const int l = 63 - __builtin_clzll(nz);
+        last_nz = lo + (uint64_t)row * 64 + (uint64_t)l;
+        before_last = run + __shfl(inc - p, l, 64);
+      }
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+      // rounding slack past the last populated tile: land in it (k_locate_tile clamps the same way)
+      const bool ok = found != ~0ull;
+      blk[s] = ok ? found : last_nz;
+      const double rest = r - (ok ? before_found : before_last);
+      resid[s] = rest > 0.0 ? rest : 0.0;
+    }
+  }
+}
+
 // marginal over up to 26 qubits; only indices with (g & fmask) == fval contribute, where
 // g = hi | i is the global index.  Small tables are pre-reduced in LDS.
 template <bool LDS>

@@ -53,10 +53,11 @@ def _bit_maps(circuit):
 
 def _unpack(ci):
     """CircuitInstruction (new style) or (op, qargs, cargs) tuple (legacy)"""
-    if hasattr(ci, "operation"):
+    try:
         return ci.operation, ci.qubits, ci.clbits
-    op, qargs, cargs = ci
-    return op, qargs, cargs
+    except AttributeError:
+        op, qargs, cargs = ci
+        return op, qargs, cargs
 
 
 def _fparams(op):
@@ -157,9 +158,15 @@ def _conjugated_mcx_shape(definition):
     mid, mq, _ = _unpack(data[f])
     if mid.name not in _MCX_NAMES or getattr(mid, "condition", None) is not None:
         return None
-    qi, _ = _bit_maps(definition)
-    if qi is None:
+    qs = getattr(definition, "qubits", None)
+    if qs is None:
         return None
+    qi = {id(b): i for i, b in enumerate(qs)}
+    mq = [qi[id(b)] for b in mq]
+    ctrls, tgt = mq[:-1], mq[-1]
+    vals = _ctrl_vals(mid, len(ctrls))
+    if f == 0:
+        return ctrls, vals, tgt
     head, tail = [], []
     for k in range(f):
         a, aq, _ = _unpack(data[k])
@@ -168,16 +175,30 @@ def _conjugated_mcx_shape(definition):
             return None
         head.append(qi[id(aq[0])])
         tail.append(qi[id(bq[0])])
-    if f and (sorted(head) != sorted(tail) or len(set(head)) != f):
+    if sorted(head) != sorted(tail) or len(set(head)) != f:
         return None
-    mq = [qi[id(b)] for b in mq]
-    ctrls, tgt = mq[:-1], mq[-1]
     if tgt in head or any(x not in ctrls for x in head):
         return None
-    vals = _ctrl_vals(mid, len(ctrls))
-    if f:
-        vals = [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)]
+    vals = [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)]
     return ctrls, vals, tgt
+
+
+_PHASE_MASKS = {}
+
+
+def _phase_mask(k, y):
+    """float mask over the 2^(k+2) table entries (controls, scratch, other) on which the triple
+    with clique state y puts its phase: other = 1 and scratch xor [controls == y] = 1"""
+    m = _PHASE_MASKS.get((k, y))
+    if m is None:
+        j = np.arange(2 ** (k + 2))
+        cbits = j & (2 ** k - 1)
+        tb = (j >> k) & 1
+        ob = (j >> (k + 1)) & 1
+        m = (ob & (tb ^ (cbits == y))).astype(np.float64)
+        m.setflags(write=False)
+        _PHASE_MASKS[(k, y)] = m
+    return m
 
 
 def _emit_phase_block(definition, qmap, out):
@@ -189,9 +210,10 @@ def _emit_phase_block(definition, qmap, out):
     n = len(data)
     if n < 3 or n % 3 or getattr(definition, "global_phase", 0):
         return False
-    qi, _ = _bit_maps(definition)
-    if qi is None:
+    qs = getattr(definition, "qubits", None)
+    if qs is None:
         return False
+    qi = {id(b): i for i, b in enumerate(qs)}
     key = None
     terms = []
     n_src = 0
@@ -202,8 +224,11 @@ def _emit_phase_block(definition, qmap, out):
         da, db = getattr(a, "definition", None), getattr(b, "definition", None)
         if da is None or db is None:
             return False
-        sa, sb = _conjugated_mcx_shape(da), _conjugated_mcx_shape(db)
-        if sa is None or sb is None:
+        sa = _conjugated_mcx_shape(da)
+        if sa is None:
+            return False
+        sb = sa if db is da else _conjugated_mcx_shape(db)
+        if sb is None:
             return False
         # map the AND's local qubits to this definition's qubits
         la = [qi[id(x)] for x in aq]
@@ -231,14 +256,13 @@ def _emit_phase_block(definition, qmap, out):
     if out._measured and out._measured.intersection(glob):
         return False
     k = len(ctrls)
-    j = np.arange(2 ** (k + 2))
-    cbits = j & (2 ** k - 1)
-    tb = (j >> k) & 1
-    ob = (j >> (k + 1)) & 1
-    ang = np.zeros(j.shape)
+    ang = None
     for vals, lam in terms:
-        y = sum(v << e for e, v in enumerate(vals))
-        ang += lam * (ob & (tb ^ (cbits == y)))
+        y = 0
+        for e, v in enumerate(vals):
+            y |= v << e
+        t = lam * _phase_mask(k, y)
+        ang = t if ang is None else ang + t
     out.ops.append(ir.Op("diag", qubits=tuple(glob), table=np.exp(1j * ang)))
     out.n_source_ops += n_src
     return True
