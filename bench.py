@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--config", type=int, default=0, help="force BASELINE configs[i] (1..4) regardless of --gpus")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--gates", action="store_true", help="gate-apply micro-benchmark (1 GPU)")
+    ap.add_argument("--no-fold", action="store_true",
+                    help="fold_fresh off: every fused gate is applied as a sweep of the full vector (k_multi passes)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
     return ap.parse_args()
 
@@ -271,7 +273,7 @@ def main():
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
-                         device=device, devices=(0,) * max(1, args.virtual_shards))
+                         device=device, devices=(0,) * max(1, args.virtual_shards), fold_fresh=not args.no_fold)
 
     main_leg = timed_leg(backend, comm, qc, args.shots, args.steps, args.warmup, options=args.option)
     elapsed, meta, agg = main_leg["elapsed"], main_leg["meta"], main_leg["agg"]
@@ -338,7 +340,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": name, "qubits": W, "shots": args.shots, "fusion": args.fusion,
+            "config": {"workload": name, "qubits": W, "shots": args.shots, "fusion": args.fusion, "fold_fresh": not args.no_fold,
                        "layout": args.layout, "state_GiB": 16.0 * 2 ** W / 2 ** 30,
                        "shard_GiB": 16.0 * 2 ** W / 2 ** 30 / max(args.virtual_shards, args.gpus),
                        "sweeps_per_step": sum(a["launches"] for k, a in agg.items() if k != "prob") // args.steps,
