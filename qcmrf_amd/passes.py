@@ -676,6 +676,8 @@ def fold_fresh(ops):
                 if not in_pop or (plus >> tg) & 1:
                     sq, st = _slice_zero(sel, np.asarray(mats).reshape(-1, 4), populated, ent=4)
                     st = st.reshape(-1, 2, 2)
+                    if not in_pop and np.array_equal(st, np.broadcast_to(np.eye(2), st.shape)):
+                        continue            # e.g. a control that needs a |0> qubit to be 1: the gate never fires
                     col = st[:, :, 0] * np.sqrt(2.0) if not in_pop else st[:, :, 0] + st[:, :, 1]
                     # table index: bits 0..k-1 the surviving selects, bit k the target
                     tab = np.concatenate([col[:, 0], col[:, 1]])

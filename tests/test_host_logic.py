@@ -346,3 +346,66 @@ def test_trajectory_through_the_backend_and_seeded():
     assert r1.metadata(0)["method"] == "trajectory" and r1.metadata(0)["live_qubits"] == 5
     p = cf.probabilities(C, qc.theta)
     assert all(p[int(k, 2)] > 0 for k in c1)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fold_fresh_random_circuits(seed):
+    """passes.fold_fresh: gates whose target nothing has touched yet become diagonal factors of
+    the initial product state.  Random circuits open with plenty of those (on |0>, on |+> after a
+    folded H, with controls on qubits that are still |0>); the rewritten program must give the
+    same state as the oracle, with and without the pass, sharded or not."""
+    nq = 8 + seed % 3
+    qc = rand_circuit(nq, 40 + 5 * seed, 1000 + seed)
+    want = oracle_state_of(qc)
+    be = QsvBackend()
+    for shards in (1, 2):
+        for fresh in (True, False):
+            ing, pl = be.compile(qc, shards, fusion=3, fold_fresh=fresh)
+            eng = NumpyEngine(ing.num_qubits, shards)
+            rec, data = program.encode(pl.ops)
+            eng.exec(rec, data)
+            assert np.abs(logical_amplitudes(eng, pl.layout, ing.num_qubits) - want).max() < 1e-12, (shards, fresh)
+
+
+def test_fold_fresh_rules():
+    """the individual rules, on hand-made op lists (logical qubits, no planner)"""
+    rs = np.random.RandomState(11)
+
+    def ru():
+        q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
+        return q
+
+    def state(ops, n):
+        eng = NumpyEngine(n)
+        program.run_stepwise(eng, ops)
+        return eng.amplitudes()
+
+    n = 6
+    mats = np.array([ru() for _ in range(4)])
+    base = [ir.op_init(0b000011),                                   # q0, q1 in |+>
+            ir.op_mux([0, 1], 2, mats),                            # fresh |0> target, populated selects
+            ir.op_u(3, ru(), ctrls=[4], vals=[0]),                 # control on |0> with value 0: always fires
+            ir.op_u(5, ru(), ctrls=[4], vals=[1]),                 # control on |0> with value 1: never fires, dropped
+            ir.op_diag([0, 4], np.exp(1j * rs.randn(4))),          # diagonal over a populated and a |0> qubit
+            ir.op_u(1, ru()),                                      # q1 selected the multiplexer: no longer |+>, cannot fold
+            ir.op_mcphase([2, 3], 0.7),
+            ir.op_x(4, ctrls=[2]),                                 # now qubit 4 gets populated, controlled by a folded target
+            ir.op_u(0, ru()),                                      # q0 has been used by factors: cannot fold
+            ir.op_u(2, ru(), ctrls=[0]),                           # touches blocked q0: cannot fold
+            ir.op_diag([3, 5], np.exp(1j * rs.randn(4)))]          # disjoint from everything blocked: still folds
+    out = passes.fold_fresh(base)
+    kinds = [o.kind for o in out]
+    assert kinds[0] == "init" and kinds.count("u") == 3 and kinds[-3:] == ["u", "u", "u"]
+    assert out[0].mask == 0b011111                                  # q2, q3, q4 populated; q5 never left |0>
+    assert all(o.kind == "diag" for o in out[1:-3])
+    assert all(((out[0].mask >> q) & 1) for o in out[1:-3] for q in o.qubits)   # no factor reads an unpopulated bit
+    # an untouched |+> target does fold (row sums)
+    plus = [ir.op_init(0b11), ir.op_u(0, ru()), ir.op_mux([0], 1, np.array([ru(), ru()]))]
+    outp = passes.fold_fresh(plus)
+    assert [o.kind for o in outp] == ["init", "diag", "diag"] and np.abs(state(outp, 2) - state(plus, 2)).max() < 1e-13
+    assert np.abs(state(out, n) - state(base, n)).max() < 1e-13
+    # nothing to fold after a dense gate has touched every qubit
+    blocked = [ir.op_init(0), ir.op_kq([0, 1, 2], np.linalg.qr(rs.randn(8, 8) + 1j * rs.randn(8, 8))[0]), ir.op_u(1, ru())]
+    assert [o.kind for o in passes.fold_fresh(blocked)] == ["init", "kq", "u"]
+    # a program that does not start with init is left alone
+    assert passes.fold_fresh(base[1:]) == base[1:]
