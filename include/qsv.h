@@ -89,6 +89,12 @@ int qsv_create_rank(int n_qubits, int world_size, int rank, int device_id, qsv_h
 int qsv_comm_unique_id(uint8_t id[QSV_UNIQUE_ID_BYTES]);
 int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES]);
 
+/* Diagnostic: bring RCCL up on one device as a 1-rank communicator and push `n_doubles` through
+ * the same grouped ncclSend/ncclRecv + stream sequence the shard exchange uses (rank 0 to itself),
+ * then compare.  Exercises the dlopen binding, communicator life cycle and call order on a box
+ * with a single GPU, where RCCL refuses two ranks on one device.  0 on success. */
+int qsv_rccl_selftest(int device_id, uint64_t n_doubles);
+
 int qsv_destroy(qsv_handle* h);
 int qsv_sync(qsv_handle* h);
 

@@ -85,6 +85,7 @@ SIGNATURES = {
     "qsv_last_error": (C.c_char_p, []),
     "qsv_version": (C.c_char_p, []),
     "qsv_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "qsv_rccl_selftest": (C.c_int, [C.c_int, C.c_uint64]),
 }
 
 _lib = None
@@ -149,6 +150,11 @@ def device_memory(device=0):
     f, t = C.c_uint64(0), C.c_uint64(0)
     _chk(load().qsv_device_memory(int(device), C.byref(f), C.byref(t)))
     return int(f.value), int(t.value)
+
+
+def rccl_selftest(device=0, n_doubles=1 << 20):
+    """1-rank RCCL bring-up + grouped send/recv to self on one device (diagnostic)"""
+    _chk(load().qsv_rccl_selftest(int(device), int(n_doubles)))
 
 
 def comm_unique_id():

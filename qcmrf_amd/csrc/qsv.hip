@@ -396,6 +396,46 @@ extern "C" int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES
   return QSV_OK;
 }
 
+extern "C" int qsv_rccl_selftest(int device_id, uint64_t n_doubles) {
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(QSV_E_BADARG, "device id %d not in [0,%d)", device_id, ndev);
+  if (n_doubles < 1 || n_doubles > (1ull << 28)) return fail(QSV_E_BADARG, "n_doubles out of range");
+  CHK(rccl_load());
+  HIPCHK(hipSetDevice(device_id));
+  ncclUniqueId uid;
+  NCCLCHK(g_rccl.GetUniqueId(&uid));
+  ncclComm_t comm = nullptr;
+  NCCLCHK(g_rccl.CommInitRank(&comm, 1, uid, 0));
+  hipStream_t st = nullptr;
+  double *a = nullptr, *b = nullptr;
+  int rc = QSV_OK;
+  std::vector<double> hin(n_doubles), hout(n_doubles, 0.0);
+  for (uint64_t i = 0; i < n_doubles; ++i) hin[i] = 0.5 * (double)i - 3.0;
+  auto body = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&a, n_doubles * sizeof(double)));
+    HIPCHK(hipMalloc(&b, n_doubles * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(a, hin.data(), n_doubles * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b, 0, n_doubles * sizeof(double), st));
+    NCCLCHK(g_rccl.GroupStart());
+    NCCLCHK(g_rccl.Send(a, n_doubles, ncclDouble, 0, comm, st));
+    NCCLCHK(g_rccl.Recv(b, n_doubles, ncclDouble, 0, comm, st));
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipMemcpyAsync(hout.data(), b, n_doubles * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n_doubles; ++i)
+      if (hout[i] != hin[i]) return fail(QSV_E_RCCL, "rccl self-test: element %llu came back as %g, sent %g", (unsigned long long)i, hout[i], hin[i]);
+    return QSV_OK;
+  };
+  rc = body();
+  if (a) hipFree(a);
+  if (b) hipFree(b);
+  if (st) hipStreamDestroy(st);
+  g_rccl.CommDestroy(comm);
+  return rc;
+}
+
 extern "C" int qsv_sync(qsv_handle* h) {
   if (!h) return fail(QSV_E_BADARG, "NULL handle");
   for (Shard& s : h->shards) {

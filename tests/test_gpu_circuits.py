@@ -554,3 +554,27 @@ def test_init_product_generator_against_numpy_engine():
         keep = pb * shots > 5
         chi = ((ob[keep] - pb[keep] * shots) ** 2 / (pb[keep] * shots)).sum() / (keep.sum() - 1)
         assert 0.8 < chi < 1.2, chi
+
+
+def test_rccl_binding_selftest():
+    """RCCL refuses two ranks on one device, so the 2-GPU exchange cannot run on the one-GPU test
+    box; what can: the dlopen binding, a 1-rank communicator and the grouped ncclSend/ncclRecv +
+    stream sequence the exchange uses, rank 0 to itself (8 MiB)."""
+    from qcmrf_amd import _lib
+    _lib.rccl_selftest(0, 1 << 20)
+
+
+def test_full_size_w34_on_one_gpu(be):
+    """BASELINE config 5 (2x7 grid, W = 34): 256 GiB of amplitudes on ONE MI355X (288 GiB) -- the
+    workload bench.py times at every N.  Default path (generator) and full-width sweeps."""
+    from qcmrf_amd import _lib
+    free, total = _lib.device_memory(0)
+    if free < 16 * 2 ** 34 + (6 << 30):
+        pytest.skip("needs 262 GiB of free HBM, device has %.0f GiB free" % (free / 2 ** 30))
+    C = gs.grid_cliques(2, 7)
+    assert cf.model_shape(C) == (14, 19, 34, 76)
+    be.close()
+    meta = _full_size_properties(be, C)
+    assert meta["n_device_ops"] == 20
+    _full_size_properties(be, C, fold_fresh=False)
+    be.run(__import__("qcmrf_amd").QCMRF([[0, 1]], [-0.1] * 4), shots=1)      # frees the 256 GiB
