@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--layout", default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (untimed-for-value) legs")
+    ap.add_argument("--variants", action="store_true", help="N > 1: run the extra legs too (default there: measured leg only)")
     ap.add_argument("--with-exchange", action="store_true", help="N>1: also run the legs that need RCCL exchanges")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="1 GPU: split the vector into this many shards on device 0 (config-4 rehearsal: real "
@@ -302,7 +303,9 @@ def main():
                                           "frac_of_8TBps": a["bytes"] / a["ms"] / 1e6 / HBM_PEAK_GBPS if a["ms"] > 0 else None}
                                       for k, a in agg.items()}}
 
-    if not args.no_variants:
+    # N > 1: the measured leg only, unless --variants asks for more -- an extra leg that failed on one
+    # rank would leave the others in a barrier and cost the whole line
+    if not args.no_variants and (world == 1 or args.variants):
         n = max(2, args.steps // 2)
         leg("full-width gate sweeps (fold_fresh off: init-fused pass + read/write k_multi passes)", n, fold_fresh=False)
         leg("full-width gate sweeps + zero tracking (opt-in: skips the provably-zero part of the vector)", n,

@@ -879,7 +879,7 @@ struct ProdFactor {
 // factor list order: nuni thread-uniform ones, then nsingle[c] factors on register bit c only
 // (c = 0..R-1), then nmulti factors on several register bits
 struct ProdCounts { int nuni; int nsingle[QSV_MULTI_MAXR]; int nmulti; };
-template <int R>
+template <int R, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_init_prod(cplx* __restrict__ amp, uint64_t nthreads, BitIns ins, RegPos rp,
                                                        LanePos lp, const ProdFactor* __restrict__ fac, ProdCounts cnt,
                                                        const cplx* __restrict__ tables, int ntab, uint64_t nonmask,
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_init_prod(cplx* __restrict__ amp, u
     uint64_t off = 0;
 #pragma unroll
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-    (pblk + off)[base_thr] = a[j];
+    if (NT) st_nt((pblk + off) + base_thr, a[j]); else (pblk + off)[base_thr] = a[j];
     psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
   }
   if (tile_sums) {
