@@ -31,6 +31,16 @@ _X2 = np.array([[0, 1], [1, 0]], dtype=np.complex128)
 SQH = 1.0 / np.sqrt(2.0)
 
 
+def _1q_qubit(op):
+    """the qubit if op is an uncontrolled one-qubit gate, else None (no matrix built)"""
+    k = op.kind
+    if k == "u" or k == "x":
+        return None if op.ctrls else op.target
+    if k == "diag" or k == "mcphase":
+        return op.qubits[0] if len(op.qubits) == 1 else None
+    return None
+
+
 def _as_1q(op):
     """(qubit, 2x2) if op is an uncontrolled one-qubit gate, else None"""
     if op.kind == "u" and not op.ctrls:
@@ -51,9 +61,9 @@ def split_leading(ops):
     (``rz sx rz`` of a lowered H, or a literal H); rest = everything else, order kept."""
     lead, closed, rest = {}, set(), []
     for op in ops:
-        one = _as_1q(op)
-        if one is not None and one[0] not in closed:
-            q, m = one
+        q = _1q_qubit(op)
+        if q is not None and q not in closed:
+            m = _as_1q(op)[1]
             lead[q] = m @ lead[q] if q in lead else np.array(m, dtype=np.complex128)
             continue
         closed.update(op.support())
@@ -91,8 +101,8 @@ def fold_init(ops, hold=None):
     # gates of folded qubits' leading runs disappear; everything else keeps its place
     closed, body = set(), []
     for op in ops:
-        one = _as_1q(op)
-        if one is not None and one[0] not in closed and one[0] in fold:
+        q = _1q_qubit(op)
+        if q is not None and q not in closed and q in fold:
             continue
         closed.update(op.support())
         body.append(op)
@@ -397,24 +407,38 @@ def fuse_mux(ops, smax=8):
 _ZERO = 1e-13
 
 
+_ROWS = {}
+
+
+def _pair_rows(n, tb, cbits, cvals):
+    """row indices (r0, r1 = r0 | 1<<tb) of an n-row matrix on which a controlled 2x2 acts; cached:
+    a lowered circuit asks for the same few patterns thousands of times"""
+    key = (n, tb, cbits, cvals)
+    hit = _ROWS.get(key)
+    if hit is None:
+        rows = np.arange(n)
+        fire = ((rows >> tb) & 1) == 0
+        for c, v in zip(cbits, cvals):
+            fire &= ((rows >> c) & 1) == v
+        r0 = rows[fire]
+        hit = _ROWS[key] = (r0, r0 | (1 << tb))
+    return hit
+
+
 def _op_on_rows(U, op, pos):
     """U <- G U for gate ``op`` acting on the row index of U; pos maps logical qubit -> row bit"""
-    rows = np.arange(U.shape[0])
     k = op.kind
     if k in ("u", "x"):
-        tb = pos[op.target]
-        fire = np.ones(rows.shape, dtype=bool)
-        for c, v in zip(op.ctrls, op.vals):
-            fire &= ((rows >> pos[c]) & 1) == v
-        r0 = rows[fire & (((rows >> tb) & 1) == 0)]
-        r1 = r0 | (1 << tb)
+        r0, r1 = _pair_rows(U.shape[0], pos[op.target], tuple(pos[c] for c in op.ctrls), tuple(op.vals))
         a, b = U[r0], U[r1]
         if k == "x":
-            U[r0], U[r1] = b, a.copy()
+            U[r0], U[r1] = b, a
         else:
             m = op.mat
             U[r0], U[r1] = m[0, 0] * a + m[0, 1] * b, m[1, 0] * a + m[1, 1] * b
-    elif k == "mcphase":
+        return U
+    rows = np.arange(U.shape[0])
+    if k == "mcphase":
         fire = np.ones(rows.shape, dtype=bool)
         for q, v in zip(op.qubits, op.vals):
             fire &= ((rows >> pos[q]) & 1) == v
@@ -486,21 +510,19 @@ def _recover(qubits, U, n_ops):
     return [ir.op_kq(qubits, U)]
 
 
-_OFFBLOCK = {}
-
-
-def _offblock_masks(k):
-    if k not in _OFFBLOCK:
-        idx = np.arange(2 ** k)
-        _OFFBLOCK[k] = [((idx >> b) & 1)[:, None] != ((idx >> b) & 1)[None, :] for b in range(k)]
-    return _OFFBLOCK[k]
+_RC = {}
 
 
 def _n_dense_bits(U):
-    """number of window bits in which U is NOT block diagonal"""
-    k = U.shape[0].bit_length() - 1
-    A = np.abs(U)
-    return sum(1 for m in _offblock_masks(k) if A[m].max() > _ZERO)
+    """number of window bits in which U is NOT block diagonal: bit b is one iff some nonzero
+    entry sits at (r, c) with bit b of r != bit b of c, i.e. iff bit b of OR(r xor c) is set"""
+    n = U.shape[0]
+    rc = _RC.get(n)
+    if rc is None:
+        idx = np.arange(n)
+        rc = _RC[n] = (idx[:, None] ^ idx[None, :])
+    x = int(np.bitwise_or.reduce(rc[np.abs(U) > _ZERO], initial=0))
+    return bin(x).count("1")
 
 
 class _DenseWindow:
