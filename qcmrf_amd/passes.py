@@ -722,11 +722,49 @@ def fold_fresh(ops):
 
 
 # --------------------------------------------------------------------------------------------
+# peephole: 1q . diag . X . diag . X . 1q on one qubit  ->  one multiplexed 2x2
+# --------------------------------------------------------------------------------------------
+def fuse_sandwich(ops):
+    """``U2 . X . D2 . X . D1 . U1`` with U1, U2 uncontrolled one-qubit gates and the two X on the same
+    qubit a, D1 and D2 diagonals over one qubit list that contains a: since X diag(d0,d1) X =
+    diag(d1,d0), the run is U2 diag(D2[s,1] D1[s,0], D2[s,0] D1[s,1]) U1 for every value s of the
+    other qubits -- one uniformly controlled 2x2.  This is the real-part-extraction block of the
+    reference (QCMRF.py:231-236: H, cU, X, cU^dg, X, H) once ingest has emitted cU as a diagonal;
+    the monomial and multiplexer windows reach the same op the long way (they stay for
+    everything that does not have exactly this shape)."""
+    out, i, n = [], 0, len(ops)
+    while i < n:
+        o = ops[i]
+        if i + 5 < n and o.kind == "u" and not o.ctrls:
+            d1, x1, d2, x2, u2 = ops[i + 1:i + 6]
+            a = o.target
+            if (d1.kind == "diag" and d2.kind == "diag" and x1.kind == "x" and x2.kind == "x" and u2.kind == "u"
+                    and not x1.ctrls and not x2.ctrls and not u2.ctrls
+                    and x1.target == a and x2.target == a and u2.target == a
+                    and d1.qubits == d2.qubits and a in d1.qubits and 2 <= len(d1.qubits) <= 9):
+                qs = d1.qubits
+                k = len(qs)
+                ax = k - 1 - qs.index(a)                   # numpy axis of table-index bit e is k-1-e
+                t1 = np.moveaxis(d1.table.reshape((2,) * k), ax, -1).reshape(-1, 2)
+                t2 = np.moveaxis(d2.table.reshape((2,) * k), ax, -1).reshape(-1, 2)
+                e = t2[:, ::-1] * t1
+                mats = np.einsum("ab,sb,bc->sac", u2.mat, e, o.mat)
+                out.append(ir.op_mux([q for q in qs if q != a], a, ir.snap(mats)))
+                i += 6
+                continue
+        out.append(o)
+        i += 1
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 def _fuse_body(ops, level, kmax, smax, lowered=False):
     head, body = ops[:1], ops[1:]
     if lowered and level >= 3:
         # basis-gate input: re-assemble the blocks first, while the gate order is still pristine
         body = fuse_dense(body)
+    if level >= 2:
+        body = fuse_sandwich(body)
     body = fuse_monomial(body, kmax=kmax)
     if level >= 2:
         body = fuse_mux(body, smax=smax)
