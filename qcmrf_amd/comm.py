@@ -25,6 +25,9 @@ class SingleProcess:
     def barrier(self):
         pass
 
+    def allgather_u64(self, arr):
+        return arr[None, :]
+
 
 class TorchDistComm:
     """torch.distributed (gloo by default: host objects only) behind the same four calls."""
@@ -59,3 +62,17 @@ class TorchDistComm:
 
     def barrier(self):
         self._dist.barrier()
+
+    def allgather_u64(self, arr):
+        """equal-length uint64 vectors of every rank -> (world, n) array, ONE collective (no pickling)"""
+        import numpy as np
+        import torch
+        src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64))
+        out = torch.empty((self.world, src.numel()), dtype=torch.int64)
+        try:
+            self._dist.all_gather_into_tensor(out, src)
+        except (RuntimeError, AttributeError):
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            self._dist.all_gather(parts, src)
+            out = torch.stack(parts)
+        return out.numpy().view(np.uint64)
