@@ -73,17 +73,22 @@ def _format_keys(values, counts, num_clbits, creg_sizes):
     one (keys x width) matrix of '0'/'1' bytes, decoded once and sliced"""
     w = max(num_clbits, 1)
     values = np.ascontiguousarray(values, dtype=np.uint64)
-    shifts = np.arange(w - 1, -1, -1, dtype=np.uint64)
-    chars = (((values[:, None] >> shifts) & np.uint64(1)) + np.uint64(48)).astype(np.uint8)
-    text = chars.tobytes().decode("ascii")
-    keys = [text[i * w:(i + 1) * w] for i in range(len(values))]
+    if w <= 64:
+        # big-endian bytes -> bits -> ASCII '0'/'1' rows, viewed as fixed-width strings in one go
+        bits = np.unpackbits(values.astype(">u8").view(np.uint8).reshape(-1, 8), axis=1)[:, 64 - w:]
+        keys = np.ascontiguousarray(bits + np.uint8(48)).view("S%d" % w).ravel().astype("U%d" % w).tolist()
+    else:
+        shifts = np.arange(w - 1, -1, -1, dtype=np.uint64)
+        chars = (((values[:, None] >> np.minimum(shifts, np.uint64(63))) & np.uint64(1)) * (shifts < 64) + np.uint64(48)).astype(np.uint8)
+        text = chars.tobytes().decode("ascii")
+        keys = [text[i * w:(i + 1) * w] for i in range(len(values))]
     if creg_sizes and len(creg_sizes) > 1:           # one group per register, last register first
         cuts, hi = [], num_clbits
         for _, size in reversed(creg_sizes):
             cuts.append((num_clbits - hi, num_clbits - hi + size))
             hi -= size
         keys = [" ".join(k[a:b] for a, b in cuts) for k in keys]
-    return dict(zip(keys, (int(c) for c in counts.tolist())))
+    return dict(zip(keys, counts.tolist()))
 
 
 class QsvBackend:
