@@ -74,6 +74,10 @@ int qsv_device_count(void);
  * card (2^34 complex128 = 256 GiB fits the 288 GiB of one MI355X). */
 int qsv_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* PCI bus id of a device ("0000:05:00.0"): two ranks that report the same id on the same host
+ * share one GPU (RCCL refuses that; the peer-mapped transport below does not mind) */
+int qsv_device_bus_id(int device_id, char* out, int len);
+
 /* One process drives n_devices shards (n_devices a power of two).  device_ids[i] is the HIP
  * device of shard i; repeating an id places several ("virtual") shards on one GPU.
  * Replaces: the state allocation inside Aer's run() (run_experiment.py:56). */
@@ -88,6 +92,20 @@ int qsv_create_rank(int n_qubits, int world_size, int rank, int device_id, qsv_h
  * side broadcasts the 128 bytes, every rank calls qsv_comm_init (collective). */
 int qsv_comm_unique_id(uint8_t id[QSV_UNIQUE_ID_BYTES]);
 int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES]);
+
+/* Peer-mapped exchange (alternative transport for qsv_create_rank handles on ONE node): every
+ * rank exports an IPC handle of its shard, the host side all-gathers the QSV_IPC_HANDLE_BYTES
+ * each and every rank attaches the others; `shm_name` names a small POSIX shared-memory segment
+ * (created by the rank that passes create != 0, before the others attach) through which a pair
+ * of ranks synchronises around an exchange.  With it a shard-bit exchange is ONE kernel per rank
+ * that swaps its half of the pairs in place, reading and writing the partner's shard directly
+ * (over xGMI between GPUs; plain HBM when two ranks share a device, which RCCL refuses) -- no
+ * staging buffers, each amplitude crosses the link once.  RCCL stays the default transport
+ * whenever every rank has a device of its own. */
+#define QSV_IPC_HANDLE_BYTES 64
+int qsv_ipc_export(qsv_handle* h, uint8_t out[QSV_IPC_HANDLE_BYTES]);
+int qsv_ipc_attach(qsv_handle* h, const uint8_t* handles /* world x QSV_IPC_HANDLE_BYTES */,
+                   const char* shm_name, int create);
 
 /* Diagnostic: bring RCCL up on one device as a 1-rank communicator and push `n_doubles` through
  * the same grouped ncclSend/ncclRecv + stream sequence the shard exchange uses (rank 0 to itself),

@@ -223,5 +223,5 @@ class NumpyEngine:
     def set_profiling(self, on): pass
     def set_option(self, name, value): pass
     def comm_init(self, uid): pass
-    def comm_bootstrap(self, comm): pass
+    def comm_bootstrap(self, comm, device=0, transport="auto"): pass
     def stats(self): return {"kinds": {}, "exchanges": self.n_exchanges, "exchange_bytes": 0.0, "fused_gates": 0}

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libqsv.so")
 MAX_CTRL = 16
 MAX_KQ = 5
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 
 K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "exchange", "multi", "multi_init", "init_prod"]
 K_COUNT = len(K_NAMES)
@@ -86,6 +87,9 @@ SIGNATURES = {
     "qsv_version": (C.c_char_p, []),
     "qsv_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qsv_rccl_selftest": (C.c_int, [C.c_int, C.c_uint64]),
+    "qsv_device_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "qsv_ipc_export": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "qsv_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_char_p, C.c_int]),
 }
 
 _lib = None
@@ -157,6 +161,12 @@ def rccl_selftest(device=0, n_doubles=1 << 20):
     _chk(load().qsv_rccl_selftest(int(device), int(n_doubles)))
 
 
+def device_bus_id(device=0):
+    buf = C.create_string_buffer(64)
+    _chk(load().qsv_device_bus_id(int(device), buf, 64))
+    return buf.value.decode()
+
+
 def comm_unique_id():
     buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
     _chk(load().qsv_comm_unique_id(buf))
@@ -210,10 +220,45 @@ class Engine:
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         _chk(self._lib.qsv_comm_init(self._h, buf))
 
-    def comm_bootstrap(self, comm):
-        """collective over ``comm``: rank 0 mints the RCCL unique id, everyone joins"""
-        uid = comm.bcast(comm_unique_id() if comm.rank == 0 else None, src=0)
-        self.comm_init(uid)
+    def device_identity(self, device):
+        """(host, PCI bus id) of a HIP device: two ranks with the same identity share one GPU"""
+        import socket
+        return socket.gethostname(), device_bus_id(device)
+
+    def comm_bootstrap(self, comm, device=0, transport="auto"):
+        """collective over ``comm``: set up the exchange transport between the ranks.
+
+        'rccl'  rank 0 mints the RCCL unique id, everyone joins (RCCL over xGMI; the default
+                whenever every rank has a GPU of its own)
+        'p2p'   every rank maps the others' shards through HIP IPC and a pair swaps in place
+        'auto'  p2p if two ranks share a device (RCCL refuses that: the one-GPU test box), else rccl"""
+        if transport == "auto":
+            ids = comm.allgather(self.device_identity(device))
+            transport = "p2p" if len(set(ids)) < len(ids) else "rccl"
+        if transport == "rccl":
+            uid = comm.bcast(comm_unique_id() if comm.rank == 0 else None, src=0)
+            self.comm_init(uid)
+        elif transport == "p2p":
+            buf = (C.c_uint8 * IPC_HANDLE_BYTES)()
+            _chk(self._lib.qsv_ipc_export(self._h, buf))
+            handles = b"".join(comm.allgather(bytes(buf)))
+            name = comm.bcast("/qsv_%d_%d" % (os.getpid(), int.from_bytes(os.urandom(4), "little")) if comm.rank == 0 else None)
+            hb = (C.c_uint8 * len(handles)).from_buffer_copy(handles)
+            if comm.rank == 0:                      # create the segment before anyone else opens it
+                _chk(self._lib.qsv_ipc_attach(self._h, hb, name.encode(), 1))
+            comm.barrier()
+            if comm.rank != 0:
+                _chk(self._lib.qsv_ipc_attach(self._h, hb, name.encode(), 0))
+            comm.barrier()
+            if comm.rank == 0:                      # every rank holds its mapping: the name can go
+                try:
+                    os.unlink("/dev/shm" + name)
+                except OSError:
+                    pass
+        else:
+            raise ValueError("transport must be 'auto', 'rccl' or 'p2p', not %r" % (transport,))
+        self.transport = transport
+        return transport
 
     def sync(self):
         _chk(self._lib.qsv_sync(self._h))

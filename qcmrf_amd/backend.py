@@ -243,7 +243,8 @@ class QsvBackend:
         for k, v in (opts["engine_options"] or {}).items():
             eng.set_option(k, v)
         if pl.n_exchanges and not eng._comm_ready:
-            eng.comm_bootstrap(comm)         # collective: RCCL communicator over all ranks
+            # collective: RCCL communicator over all ranks, or peer-mapped shards (ranks sharing a GPU)
+            eng.comm_bootstrap(comm, device=opts["device"], transport=opts.get("exchange", "auto"))
             eng._comm_ready = True
         if opts["profile"]:
             eng.set_profiling(True)

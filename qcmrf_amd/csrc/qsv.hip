@@ -6,6 +6,13 @@
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -139,6 +146,11 @@ struct qsv_handle {
   bool multiproc = false;
   int rank = 0;
   ncclComm_t comm = nullptr;
+  // peer-mapped transport: the other ranks' shards (IPC) and the arrival counters shared with them
+  std::vector<cplx*> peer_amp;
+  std::atomic<uint64_t>* ipc_arrive = nullptr;   // one counter per rank, QSV_IPC_SLOT apart
+  size_t ipc_map_bytes = 0;
+  uint64_t ipc_seq = 0;
   std::vector<Shard> shards;     // shards owned by this process
   qsv_stats stats;
   bool profiling = false;
@@ -284,6 +296,15 @@ extern "C" int qsv_device_memory(int device_id, uint64_t* free_bytes, uint64_t* 
   return QSV_OK;
 }
 
+extern "C" int qsv_device_bus_id(int device_id, char* out, int len) {
+  if (!out || len < 16) return fail(QSV_E_BADARG, "bus id buffer too small");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(QSV_E_BADARG, "device id %d not in [0,%d)", device_id, ndev);
+  HIPCHK(hipDeviceGetPCIBusId(out, len, device_id));
+  return QSV_OK;
+}
+
 static int create_common(int n_qubits, int P, qsv_handle** out, qsv_handle** hh) {
   if (!out) return fail(QSV_E_BADARG, "out is NULL");
   const int g = ilog2_exact(P);
@@ -324,6 +345,9 @@ extern "C" int qsv_destroy(qsv_handle* h) {
   if (h->t0) hipEventDestroy(h->t0);
   if (h->t1) hipEventDestroy(h->t1);
   if (h->comm && g_rccl.lib) g_rccl.CommDestroy(h->comm);
+  for (size_t r = 0; r < h->peer_amp.size(); ++r)
+    if (h->peer_amp[r] && (int)r != h->rank) hipIpcCloseMemHandle(h->peer_amp[r]);
+  if (h->ipc_arrive) munmap((void*)h->ipc_arrive, h->ipc_map_bytes);
   delete h;
   return QSV_OK;
 }
@@ -393,6 +417,62 @@ extern "C" int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES
   ncclUniqueId uid;
   memcpy(&uid, id, QSV_UNIQUE_ID_BYTES);
   NCCLCHK(g_rccl.CommInitRank(&h->comm, h->P, uid, h->rank));
+  return QSV_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// peer-mapped (IPC) transport
+// ------------------------------------------------------------------------------------------
+#define QSV_IPC_SLOT 8            // uint64 counters per rank (one 64-byte line each)
+
+extern "C" int qsv_ipc_export(qsv_handle* h, uint8_t out[QSV_IPC_HANDLE_BYTES]) {
+  if (!h || !out) return fail(QSV_E_BADARG, "NULL argument");
+  static_assert(sizeof(hipIpcMemHandle_t) <= QSV_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  CHK(shard_set(h->shards[0]));
+  hipIpcMemHandle_t hd;
+  HIPCHK(hipIpcGetMemHandle(&hd, h->shards[0].amp));
+  memset(out, 0, QSV_IPC_HANDLE_BYTES);
+  memcpy(out, &hd, sizeof hd);
+  return QSV_OK;
+}
+
+extern "C" int qsv_ipc_attach(qsv_handle* h, const uint8_t* handles, const char* shm_name, int create) {
+  if (!h || !handles || !shm_name) return fail(QSV_E_BADARG, "NULL argument");
+  if (!h->multiproc) return QSV_OK;
+  if (!h->peer_amp.empty()) return QSV_OK;
+  CHK(shard_set(h->shards[0]));
+  const size_t bytes = (size_t)h->P * QSV_IPC_SLOT * sizeof(uint64_t);
+  const int fd = shm_open(shm_name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+  if (fd < 0) return fail(QSV_E_HIP, "shm_open(%s) failed", shm_name);
+  if (create && ftruncate(fd, (off_t)bytes) != 0) { close(fd); return fail(QSV_E_HIP, "ftruncate(%s) failed", shm_name); }
+  void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return fail(QSV_E_HIP, "mmap(%s) failed", shm_name);
+  h->ipc_arrive = reinterpret_cast<std::atomic<uint64_t>*>(m);     // a fresh segment reads as zeros
+  h->ipc_map_bytes = bytes;
+  h->peer_amp.assign(h->P, nullptr);
+  h->peer_amp[h->rank] = h->shards[0].amp;
+  for (int r = 0; r < h->P; ++r) {
+    if (r == h->rank) continue;
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, handles + (size_t)r * QSV_IPC_HANDLE_BYTES, sizeof hd);
+    void* p = nullptr;
+    HIPCHK(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+    h->peer_amp[r] = reinterpret_cast<cplx*>(p);
+  }
+  return QSV_OK;
+}
+
+// both ranks of a pair call this the same number of times; returns once the peer has arrived too
+static int ipc_pair_barrier(qsv_handle* h, int peer) {
+  const uint64_t seq = ++h->ipc_seq;
+  h->ipc_arrive[(size_t)h->rank * QSV_IPC_SLOT].store(seq, std::memory_order_release);
+  const auto t0 = std::chrono::steady_clock::now();
+  while (h->ipc_arrive[(size_t)peer * QSV_IPC_SLOT].load(std::memory_order_acquire) < seq) {
+    sched_yield();
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+      return fail(QSV_E_HIP, "rank %d waited 120 s for rank %d at exchange step %llu", h->rank, peer, (unsigned long long)seq);
+  }
   return QSV_OK;
 }
 

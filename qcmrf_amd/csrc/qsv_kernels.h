@@ -307,6 +307,21 @@ __global__ __launch_bounds__(QSV_TPB) void k_swap_shards(cplx* __restrict__ A, c
   }
 }
 
+// the same over a sub-range [p0, p0 + cnt) of the half-space: each rank of a pair that maps the
+// partner's shard (IPC) swaps its own half of the pairs
+__global__ __launch_bounds__(QSV_TPB) void k_swap_shards_range(cplx* __restrict__ A, cplx* __restrict__ B,
+                                                               uint64_t p0, uint64_t cnt, int j) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  const uint64_t jbit = 1ull << j, lo = jbit - 1ull;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
+    const uint64_t p = p0 + q;
+    const uint64_t i = ((p >> j) << (j + 1)) | (p & lo);
+    const cplx x = A[i | jbit], y = B[i];
+    A[i | jbit] = y;
+    B[i] = x;
+  }
+}
+
 // pack / unpack the half of a shard whose bit j equals v into / from a contiguous buffer
 // (chunk [p0, p0+cnt) of the 2^(L-1) half-space) -- staging for peer copies and RCCL.
 __global__ __launch_bounds__(QSV_TPB) void k_pack(const cplx* __restrict__ amp, cplx* __restrict__ buf,
