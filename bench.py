@@ -298,6 +298,7 @@ def main():
         m = r.metadata(0)
         variants[name] = {"shots_per_s": args.shots * n / dt, "ms_per_step": dt / n * 1e3,
                           "device_ops": m["n_device_ops"], "evolve_ms": m["time_evolve"] * 1e3,
+                          "exchanges_per_step": m["n_exchanges"],
                           "kernels": {k: {"launches_per_step": a["launches"] / n, "avg_ms": a["ms"] / a["launches"],
                                           "GBps": a["bytes"] / a["ms"] / 1e6 if a["ms"] > 0 else None,
                                           "frac_of_8TBps": a["bytes"] / a["ms"] / 1e6 / HBM_PEAK_GBPS if a["ms"] > 0 else None}
@@ -310,9 +311,12 @@ def main():
         leg("full-width gate sweeps (fold_fresh off: init-fused pass + read/write k_multi passes)", n, fold_fresh=False)
         leg("full-width gate sweeps + zero tracking (opt-in: skips the provably-zero part of the vector)", n,
             fold_fresh=False, engine_options={"zero_tracking": 1})
-        if world == 1 or args.with_exchange:
-            # N > 1: the unfused stream needs shard-bit exchanges (RCCL); opt-in there, because a
-            # first-ever RCCL bring-up must not be able to take the main measurement down with it
+        if world > 1 and args.with_exchange:
+            # ancillas (the dense targets) on the shard bits: every late clique costs a half-shard
+            # exchange (RCCL between GPUs, peer-mapped when ranks share one)
+            leg("reference layout (qubit q on bit q), fold_fresh off: shard-bit exchanges", 2, fold_fresh=False,
+                layout="reference", engine_options={"zero_tracking": 0})
+        if world == 1:
             leg("unfused reference-order gate stream (fusion=0)", 1, fusion=0, engine_options={"zero_tracking": 0})
         if world == 1:
             from qcmrf_amd.transpile import transpile
