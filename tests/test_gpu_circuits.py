@@ -578,3 +578,21 @@ def test_full_size_w34_on_one_gpu(be):
     assert meta["n_device_ops"] == 20
     _full_size_properties(be, C, fold_fresh=False)
     be.run(__import__("qcmrf_amd").QCMRF([[0, 1]], [-0.1] * 4), shots=1)      # frees the 256 GiB
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_virtual_shards_default_path_generator(be, P):
+    """the default (folded) path on P shards: every factor with a qubit on a shard bit is sliced
+    per shard and each shard runs its own k_init_prod (L >= 14 local qubits); no exchanges"""
+    from qcmrf_amd import QCMRF
+    C = gs.chain_cliques(10)                       # n = 10, m = 9, W = 20
+    th = random_theta(cf.model_shape(C)[3], seed=10 + P)
+    for layout in ("auto", "reference"):
+        amp, meta = run_state(be, QCMRF(C, th), layout=layout, devices=(0,) * P)
+        assert meta["n_shards"] == P and meta["n_exchanges"] == 0
+        assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+        kinds = be.last_engine.stats()["kinds"]
+    counts = be.run(QCMRF(C, th), shots=4000, seed_simulator=2, devices=(0,) * P).result().get_counts()
+    p = cf.probabilities(C, th)
+    assert sum(counts.values()) == 4000 and all(p[int(k, 2)] > 0 for k in counts)
+    be.run(QCMRF([[0, 1]], [-0.1] * 4), shots=1)
