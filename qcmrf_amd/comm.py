@@ -32,7 +32,7 @@ class SingleProcess:
 class TorchDistComm:
     """torch.distributed (gloo by default: host objects only) behind the same four calls."""
 
-    def __init__(self, backend="gloo", init=True):
+    def __init__(self, backend="gloo", init=True, timeout_s=None):
         import torch.distributed as dist
         self._dist = dist
         if init and not dist.is_initialized():
@@ -43,7 +43,11 @@ class TorchDistComm:
             saved = os.dup(1)
             try:
                 os.dup2(2, 1)
-                dist.init_process_group(backend=backend)
+                if timeout_s:
+                    import datetime
+                    dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
+                else:
+                    dist.init_process_group(backend=backend)
             finally:
                 os.dup2(saved, 1)
                 os.close(saved)
