@@ -71,7 +71,8 @@ CPU_SAMPLE_QUBITS = 28          # 4 GiB: the widest state the plain-C CPU leg is
 
 def workload(args, hbm_total):
     """One circuit for every N (strong scaling): BASELINE configs[4], the 34-qubit grid MRF
-    (256 GiB of amplitudes), whenever ONE device can hold it -- an MI355X has 288 GiB -- so that
+    (256 GiB of amplitudes), whenever ONE device can hold it right now (free HBM of rank 0's device;
+    an MI355X has 288 GiB) -- so that
     value(N) / value(1) is the 1 -> N speed-up "at 34 qubits" the north star asks for; otherwise the
     widest grid MRF one device holds.  --config / --qubits override."""
     from qcmrf_amd import workloads as wl
@@ -269,7 +270,7 @@ def main():
 
     comm = TorchDistComm("gloo", timeout_s=600) if world > 1 else SingleProcess()
     device = local_rank % max(1, n_dev)
-    hbm_total = comm.bcast(_lib.device_memory(device)[1] if rank == 0 else None)
+    hbm_total = comm.bcast(_lib.device_memory(device)[0] if rank == 0 else None)    # FREE bytes on rank 0's device
     name, cliques, theta = workload(args, hbm_total)
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
