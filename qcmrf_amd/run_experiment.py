@@ -15,6 +15,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import sys
+import time
 
 import numpy as np
 
@@ -48,8 +50,12 @@ def main(argv=None):
         CIRCS = transpile(CIRCS, basis_gates=['cx', 'id', 'rz', 'sx', 'x'])
 
     simulator = Aer.get_backend('qasm_simulator')
+    t0 = time.perf_counter()
     result = simulator.run(CIRCS, shots=args.shots, seed_simulator=args.seed_simulator).result()
     counts = result.get_counts()
+    dt = time.perf_counter() - t0
+    print("%d circuits x %d shots: %.3f s in run().result().get_counts() (%.2f ms per circuit)"
+          % (len(CIRCS), args.shots, dt, dt / len(CIRCS) * 1e3), file=sys.stderr)
     with open(os.path.join(args.outdir, "result_simulation_" + str(args.scale) + ".json"), "w") as f:
         f.write(json.dumps(counts, indent=4))
     return counts
