@@ -163,7 +163,8 @@ struct qsv_handle {
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   int opt_pair_variant = 0;           // experiments: see run_single
   int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
-  int opt_init_prod_r = 5;            // amplitudes per thread of the generator: 2^4, 2^5 or 2^6
+  int opt_init_prod_bit0 = 0;         // first register bit of the generator: 0 by shard size (default), < 0 the top bits, 6 bits 6.. + lane map
+  int opt_init_prod_r = 0;            // amplitudes per thread of the generator, log2: 0 by shard size (default), else 3..6
   int opt_init_prod = 1;              // init followed by diagonals only -> k_init_prod (write-only generator)
   int opt_pass_hints = 1;             // honour QSV_OPF_NEW_PASS (planner-chosen pass boundaries)
   int opt_lane_map = 1;               // access pattern of passes without borrowed lanes: 0 plain, 1 auto, else explicit 5-bit fields

@@ -55,6 +55,7 @@ LANE_BITS = 6      # address bits 0..5 are the lane id of a wavefront load (1 Ki
 MULTI_R = 5        # register targets per k_multi pass (libqsv option multi_r)
 DYN_LANES = 3      # lane bits 3..5 that libqsv lends to further targets of a pass (option dyn_lanes)
 STATIC_LOW = 3     # lane bits 0..2: never lent (one 128-byte line per lane group)
+GEN_TOP_MIN_L = 33 # k_init_prod keeps the top bits of a shard in registers from this many local qubits on
 
 
 def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn_lanes=DYN_LANES, want_heads=False):
@@ -140,19 +141,27 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
         reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
     if not dense and L >= 14:
         # nothing left but the initial product state and its diagonal factors (passes.fold_fresh):
-        # libqsv's generator keeps bits 6..10 in registers and multiplies a factor per AMPLITUDE
-        # if it touches one of them, per THREAD otherwise -- give those bits the qubits the fewest
-        # factors touch (for a QCMRF circuit: ancillas, one factor each)
-        uses = {q: 0 for q in quiet_u}
+        # libqsv's generator multiplies a factor per AMPLITUDE if it touches one of its register
+        # bits, per THREAD otherwise -- give those bits the qubits the fewest factors touch (a qubit
+        # that stays |0> touches none; for a QCMRF circuit then the ancillas, one factor each).
+        # Which bits those are follows the shard size exactly as in libqsv (flush_init_product):
+        # the top bits of a shard of >= 2^33 amplitudes, bits 6..10 below that.
+        cand = quiet_u + quiet_z
+        uses = {q: 0 for q in cand}
         for op in ops:
             if op.kind in ("diag", "mcphase"):
                 for q in op.qubits:
                     if q in uses:
                         uses[q] += 1
-        regq = sorted(sorted(quiet_u, key=lambda q: (uses[q], -q))[:MULTI_R])
-        others = [q for q in quiet_u if q not in regq]
-        if len(others) >= LANE_BITS and len(regq) == MULTI_R:
-            quiet_u = others[:LANE_BITS] + regq + others[LANE_BITS:]
+        regq = sorted(sorted(cand, key=lambda q: (uses[q], -q))[:MULTI_R], key=lambda q: (-uses[q], q))
+        if len(cand) - len(regq) >= LANE_BITS:
+            if L >= GEN_TOP_MIN_L:
+                quiet_u = [q for q in quiet_u if q not in regq]
+                quiet_z = [q for q in quiet_z if q not in regq] + regq      # highest local positions, fewest uses on top
+            else:
+                others = [q for q in quiet_u if q not in regq]
+                quiet_z = [q for q in quiet_z if q not in regq]
+                quiet_u = others[:LANE_BITS] + regq + others[LANE_BITS:]
     n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - nd), len(quiet_u))
     # static lane targets take the lowest bits: bits 3..5 stay free to be lent out
     order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...
