@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--layout", default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (untimed-for-value) legs")
-    ap.add_argument("--variants", action="store_true", help="N > 1: run the extra legs too (default there: measured leg only)")
-    ap.add_argument("--with-exchange", action="store_true", help="N>1: also run the legs that need RCCL exchanges")
+    ap.add_argument("--variants", action="store_true", help="N > 1: run every extra leg (default there: the measured leg + the full-width-sweep leg)")
+    ap.add_argument("--with-exchange", action="store_true", help="N > 1, with --variants: also the reference-layout leg, which needs shard-bit exchanges "
+                                                            "(RCCL between GPUs, peer-mapped shards when ranks share one)")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="1 GPU: split the vector into this many shards on device 0 (config-4 rehearsal: real "
                          "shard-bit resolution and exchange kernels, device copies instead of xGMI)")
