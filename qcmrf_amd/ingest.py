@@ -86,9 +86,19 @@ def _h_phase(lam):
     tab = np.array([1.0, np.exp(1j * lam)], dtype=np.complex128)
     return lambda ops, op, q: ops.append(ir.Op("diag", qubits=(q[0],), table=tab))
 def _h_p(ops, op, q): ops.append(ir.op_phase1(q[0], _fparams(op)[0]))
+_RZ_TABLES = {}
+
+
 def _h_rz(ops, op, q):
     lam = _fparams(op)[0]
-    ops.append(ir.op_diag([q[0]], [np.exp(-0.5j * lam), np.exp(0.5j * lam)]))
+    tab = _RZ_TABLES.get(lam)            # a lowered circuit repeats a handful of angles thousands of times
+    if tab is None:
+        if len(_RZ_TABLES) > 4096:
+            _RZ_TABLES.clear()
+        tab = np.array([np.exp(-0.5j * lam), np.exp(0.5j * lam)], dtype=np.complex128)
+        tab.setflags(write=False)
+        _RZ_TABLES[lam] = tab
+    ops.append(ir.Op("diag", qubits=(q[0],), table=tab))
 def _h_rx(ops, op, q): ops.append(ir.op_u(q[0], ir.rx(_fparams(op)[0]), label="rx"))
 def _h_ry(ops, op, q): ops.append(ir.op_u(q[0], ir.ry(_fparams(op)[0]), label="ry"))
 def _h_u(ops, op, q): ops.append(ir.op_u(q[0], ir.u3(*_fparams(op)[:3]), label="u"))
