@@ -367,6 +367,17 @@ def main():
             "roofline": roof,
         }
         line["variants"] = variants
+        # the same circuit with every fused gate swept over the full vector (fold_fresh off): the
+        # read+write k_multi pass is the "gate-apply sweep" of BASELINE.json's metric
+        for vname, v in variants.items():
+            km = v.get("kernels", {}).get("multi") if vname.startswith("full-width gate sweeps (") else None
+            if km and km.get("GBps"):
+                line["roofline_gate_sweeps"] = {
+                    "bound": "hbm", "kernel": "k_multi", "achieved": km["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": km["GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("multi", W),
+                    "avg_launch_ms": km["avg_ms"], "launches_per_step": km["launches_per_step"],
+                    "shots_per_s": v["shots_per_s"], "ms_per_step": v["ms_per_step"],
+                    "note": "variant, not part of `value`: fold_fresh=False"}
         if other:
             line["other_configs"] = other
         if args.gpus == 1 and not args.no_cpu:
