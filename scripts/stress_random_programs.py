@@ -8,88 +8,99 @@ import numpy as np
 from qcmrf_amd import _lib, ir, program
 from oracle.sharded_numpy import NumpyEngine
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-bad = 0
-engines = {}
-for case in range(n_cases):
-    W = int(rs.choice([14, 15, 16, 17]))
-    P = int(rs.choice([1, 1, 2, 4]))
-    key = (W, P)
-    if key not in engines:
-        engines[key] = _lib.Engine(W, devices=(0,) * P)
-    eng = engines[key]
-    style = rs.randint(0, 4)          # 0 rx-like simple, 1 general simple, 2 mixed general, 3 init + diagonals
-    def mat():
-        if style == 0:
-            a = rs.rand() * 3
-            return np.array([[np.cos(a), -1j * np.sin(a)], [-1j * np.sin(a), np.cos(a)]])
-        q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
-        return q
-    ops = []
-    mask = 0
-    for q in range(W):
-        if rs.rand() < 0.7:
-            mask |= 1 << q
-    if rs.rand() < 0.7 or style == 3:
-        ops.append(ir.op_init(mask))
-    for _ in range(int(rs.randint(3, 26))):
-        k = rs.randint(0, 10)
-        qs = [int(x) for x in rs.permutation(W)[:4]]
-        L = W - (P.bit_length() - 1)
-        if qs[0] >= L:                                  # dense targets must be local to a shard
-            qs[0] = int(rs.choice([q for q in range(L) if q not in qs[1:]]))
-        if style == 3:
-            kk = int(rs.randint(1, 5))
-            ops.append(ir.op_diag(qs[:kk], np.exp(1j * rs.randn(2 ** kk)) * (0.5 + rs.rand(2 ** kk))))
-        elif style in (0, 1) or k < 5:
-            nsel = int(rs.randint(0, 4))
-            sel = qs[1:1 + nsel]
-            if style in (0, 1):
-                # simple passes need selects that are never targets: take them from the top bits
-                sel = [W - 1 - i for i in range(nsel) if W - 1 - i != qs[0]]
-            ops.append(ir.op_mux(sel, qs[0], np.array([mat() for _ in range(2 ** len(sel))])) if sel else ir.op_u(qs[0], mat()))
-            if style in (0, 1) and qs[0] >= W - 3:
-                ops.pop()
-        elif k in (5, 6):
-            nc = int(rs.randint(0, 3))
-            ops.append(ir.op_x(qs[0], ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
-        elif k == 7:
-            kk = int(rs.randint(1, 4))
-            ops.append(ir.op_diag(qs[:kk], np.exp(1j * rs.randn(2 ** kk))))
-        elif k == 8:
-            kk = int(rs.randint(1, 4))
-            ops.append(ir.op_mcphase(qs[:kk], float(rs.randn()), vals=[int(v) for v in rs.randint(0, 2, size=kk)]))
-        else:
-            nc = int(rs.randint(0, 3))
-            ops.append(ir.op_u(qs[0], mat(), ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
-        if rs.rand() < 0.1 and ops[-1].kind != "init":
-            ops[-1].new_pass = True
-    ops = [o for o in ops if o is not None]
-    opts = {"multi_r": int(rs.choice([5, 5, 5, 4, 6, 3])), "dyn_lanes": int(rs.choice([3, 3, 0, 1, 2])),
-            "lane_map": int(rs.choice([1, 1, 0])), "lane_targets": int(rs.choice([1, 1, 1, 0])),
-            "zero_tracking": int(rs.choice([0, 0, 0, 1])), "init_prod": int(rs.choice([1, 1, 0])),
-            "pass_hints": int(rs.choice([1, 1, 0])), "fused_sums": int(rs.choice([1, 0]))}
-    for kname, v in opts.items():
-        eng.set_option(kname, v)
-    rec, data = program.encode(ops)
-    ref = NumpyEngine(W, P)
-    if ops[0].kind != "init":
-        ref.init_uniform((1 << W) - 1)
-        eng.init_uniform((1 << W) - 1)
-    ref.exec(rec, data)
-    eng.exec(rec, data)
-    want = ref.amplitudes()
-    got = eng.amplitudes()
-    err = float(np.abs(got - want).max())
-    tol = 1e-12 * max(1.0, float(np.abs(want).max()))
-    nrm_ref = float((np.abs(want) ** 2).sum())
-    nerr = abs(eng.norm() - nrm_ref)
-    if err > tol or nerr > 1e-10 * max(1.0, nrm_ref):
-        bad += 1
-        print("MISMATCH case %d W=%d P=%d style=%d err=%.3e normerr=%.3e opts=%s" % (case, W, P, style, err, nerr, opts), flush=True)
-        print("   ops:", [repr(o) + ("*" if o.new_pass else "") for o in ops], flush=True)
-    if case % 50 == 49:
-        print("... %d cases, %d mismatches" % (case + 1, bad), flush=True)
-print("done: %d cases, %d mismatches" % (n_cases, bad))
-sys.exit(1 if bad else 0)
+
+
+def run(n_cases=300, seed=7, verbose=True):
+    """returns the number of mismatching programs"""
+    rs = np.random.RandomState(seed)
+    bad = 0
+    engines = {}
+    for case in range(n_cases):
+        W = int(rs.choice([14, 15, 16, 17]))
+        P = int(rs.choice([1, 1, 2, 4]))
+        key = (W, P)
+        if key not in engines:
+            engines[key] = _lib.Engine(W, devices=(0,) * P)
+        eng = engines[key]
+        style = rs.randint(0, 4)          # 0 rx-like simple, 1 general simple, 2 mixed general, 3 init + diagonals
+        def mat():
+            if style == 0:
+                a = rs.rand() * 3
+                return np.array([[np.cos(a), -1j * np.sin(a)], [-1j * np.sin(a), np.cos(a)]])
+            q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
+            return q
+        ops = []
+        mask = 0
+        for q in range(W):
+            if rs.rand() < 0.7:
+                mask |= 1 << q
+        if rs.rand() < 0.7 or style == 3:
+            ops.append(ir.op_init(mask))
+        for _ in range(int(rs.randint(3, 26))):
+            k = rs.randint(0, 10)
+            qs = [int(x) for x in rs.permutation(W)[:4]]
+            L = W - (P.bit_length() - 1)
+            if qs[0] >= L:                                  # dense targets must be local to a shard
+                qs[0] = int(rs.choice([q for q in range(L) if q not in qs[1:]]))
+            if style == 3:
+                kk = int(rs.randint(1, 5))
+                ops.append(ir.op_diag(qs[:kk], np.exp(1j * rs.randn(2 ** kk)) * (0.5 + rs.rand(2 ** kk))))
+            elif style in (0, 1) or k < 5:
+                nsel = int(rs.randint(0, 4))
+                sel = qs[1:1 + nsel]
+                if style in (0, 1):
+                    # simple passes need selects that are never targets: take them from the top bits
+                    sel = [W - 1 - i for i in range(nsel) if W - 1 - i != qs[0]]
+                ops.append(ir.op_mux(sel, qs[0], np.array([mat() for _ in range(2 ** len(sel))])) if sel else ir.op_u(qs[0], mat()))
+                if style in (0, 1) and qs[0] >= W - 3:
+                    ops.pop()
+            elif k in (5, 6):
+                nc = int(rs.randint(0, 3))
+                ops.append(ir.op_x(qs[0], ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
+            elif k == 7:
+                kk = int(rs.randint(1, 4))
+                ops.append(ir.op_diag(qs[:kk], np.exp(1j * rs.randn(2 ** kk))))
+            elif k == 8:
+                kk = int(rs.randint(1, 4))
+                ops.append(ir.op_mcphase(qs[:kk], float(rs.randn()), vals=[int(v) for v in rs.randint(0, 2, size=kk)]))
+            else:
+                nc = int(rs.randint(0, 3))
+                ops.append(ir.op_u(qs[0], mat(), ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
+            if rs.rand() < 0.1 and ops[-1].kind != "init":
+                ops[-1].new_pass = True
+        ops = [o for o in ops if o is not None]
+        opts = {"multi_r": int(rs.choice([5, 5, 5, 4, 6, 3])), "dyn_lanes": int(rs.choice([3, 3, 0, 1, 2])),
+                "lane_map": int(rs.choice([1, 1, 0])), "lane_targets": int(rs.choice([1, 1, 1, 0])),
+                "zero_tracking": int(rs.choice([0, 0, 0, 1])), "init_prod": int(rs.choice([1, 1, 0])),
+                "pass_hints": int(rs.choice([1, 1, 0])), "fused_sums": int(rs.choice([1, 0]))}
+        for kname, v in opts.items():
+            eng.set_option(kname, v)
+        rec, data = program.encode(ops)
+        ref = NumpyEngine(W, P)
+        if ops[0].kind != "init":
+            ref.init_uniform((1 << W) - 1)
+            eng.init_uniform((1 << W) - 1)
+        ref.exec(rec, data)
+        eng.exec(rec, data)
+        want = ref.amplitudes()
+        got = eng.amplitudes()
+        err = float(np.abs(got - want).max())
+        tol = 1e-12 * max(1.0, float(np.abs(want).max()))
+        nrm_ref = float((np.abs(want) ** 2).sum())
+        nerr = abs(eng.norm() - nrm_ref)
+        if err > tol or nerr > 1e-10 * max(1.0, nrm_ref):
+            bad += 1
+            print("MISMATCH case %d W=%d P=%d style=%d err=%.3e normerr=%.3e opts=%s" % (case, W, P, style, err, nerr, opts), flush=True)
+            print("   ops:", [repr(o) + ("*" if o.new_pass else "") for o in ops], flush=True)
+        if case % 50 == 49 and verbose:
+            print("... %d cases, %d mismatches" % (case + 1, bad), flush=True)
+    for e in engines.values():
+        e.close()
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    print("done: %d cases, %d mismatches" % (n, bad))
+    sys.exit(1 if bad else 0)

@@ -236,3 +236,18 @@ def test_errors_are_loud(lib):
     with lib.Engine(6, devices=(0, 0)) as e:        # target on the shard bit must be refused
         with pytest.raises(RuntimeError):
             e.apply_1q(5, np.eye(2))
+
+
+@pytest.mark.parametrize("seed", [7, 21])
+def test_random_programs_differential(seed):
+    """scripts/stress_random_programs.py: 200 random programs per seed (table ops with RX-like or
+    general matrices, controlled gates, X, phases, diagonals, leading init or not, random pass
+    hints, 1/2/4 virtual shards, random engine options: tile width, borrowed lanes, lane map, zero
+    tracking, generator on/off) through qsv_exec against the numpy engine, amplitudes 1e-12."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("stress_random_programs", os.path.join(ROOT, "scripts", "stress_random_programs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(200, seed, verbose=False) == 0
