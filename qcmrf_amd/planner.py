@@ -104,7 +104,7 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
     # Targets are dealt in first-use order: per pass the register (+ borrowed) quota goes to
     # positions >= 6, then that pass's share of the static quota to lane positions.  The borrowed
     # form is chosen when it saves a pass: 19 cliques (W = 34) 3 -> 2 passes.
-    lane_t, reg_t = [], list(dense)
+    lane_t, reg_t, top_t = [], list(dense), []
     nd = len(dense)
     pass_heads = []          # first dense target of every pass after the first
     if lane_targets and nd > MULTI_R and L >= 12:
@@ -138,6 +138,12 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
         # Positions: the read+write passes take the low bits (measured at W = 34,
         # scripts/placement_sweep.py: the same pass runs at 5.4 TB/s on bits 6..13 and 5.05 TB/s on
         # 14..21), the write-only first pass -- indifferent to where its targets sit -- the block above
+        # ... and on a shard of >= 2^33 amplitudes the LAST pass keeps its register targets on the
+        # top bits of the shard (5.78 TB/s against 5.42 with them on bits 6..10, same gates,
+        # profiles/r01s2_placement_top34.log); its borrowed-lane targets stay low
+        if L >= GEN_TOP_MIN_L and n_pass >= 2 and len(big[-1]) >= MULTI_R:
+            top_t = big[-1][:MULTI_R]
+            big[-1] = big[-1][MULTI_R:]
         reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
     if not dense and L >= 14:
         # nothing left but the initial product state and its diagonal factors (passes.fold_fresh):
@@ -164,7 +170,7 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
                 quiet_u = others[:LANE_BITS] + regq + others[LANE_BITS:]
     n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - nd), len(quiet_u))
     # static lane targets take the lowest bits: bits 3..5 stay free to be lent out
-    order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z   # physical 0, 1, 2, ...
+    order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z + top_t   # physical 0, 1, 2, ...
     lay = [0] * n_qubits
     for p, q in enumerate(order):
         lay[q] = p
