@@ -812,13 +812,38 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     if constexpr (R <= 4) asm volatile("" : "+s"(ob[c]));   // pinning costs registers R = 5, 6 do not have
   }
   cplx a[1 << R];
+  int list0_done = 0;
   if (INIT) {
+    // Every register bit of a fused QCMRF pass is a fresh |0> target: the tile starts as ONE
+    // nonzero amplitude per lane (j = 0).  The first round's list ops (lane gates, diagonals) map
+    // zeros to zeros, so they are applied to that scalar BEFORE the tile exists -- 4 shuffles per
+    // lane gate instead of 128, and nothing for a write-only pass to hide (three lane gates cost
+    // 12 ms of a 55 ms pass at 34 qubits otherwise).  No tile register is live across this branch.
+    cplx f = make_double2(((base & nonmask) == 0) ? initval : 0.0, 0.0);
+    if constexpr (MODE == 2) {
+      bool all_dead = R > 0;
+#pragma unroll
+      for (int c = 0; c < R; ++c) all_dead = all_dead && (ob[c] & nonmask);
+      if (all_dead && nrounds > 0) {
+        const MultiSlot sl = slots[0];
+        for (int d = 0; d < sl.ndiag; ++d) {
+          const MultiOp& op = ops[sl.first + d];
+          const uint32_t jt = multi_jt(op, base);
+          const bool up = (threadIdx.x >> op.bit) & 1;
+          const cplx* mp = lt + op.tab + 4 * jt;
+          const double c = up ? mp[3].x : mp[0].x, sn = up ? mp[2].y : mp[1].y;
+          const double ox = __shfl_xor(f.x, 1 << op.bit, 64), oy = __shfl_xor(f.y, 1 << op.bit, 64);
+          f = make_double2(fma(c, f.x, -sn * oy), fma(c, f.y, sn * ox));
+        }
+        list0_done = 1;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
       uint64_t off = 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-      a[j] = make_double2((((base | off) & nonmask) == 0) ? initval : 0.0, 0.0);
+      a[j] = ((off & nonmask) == 0) ? f : make_double2(0.0, 0.0);
     }
   } else if (zreg == 0) {                       // the common case: no branch between the loads
 #pragma unroll
@@ -843,7 +868,8 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     const MultiSlot* rs = slots + r * NS;
     {
       const MultiSlot sl = rs[0];
-      for (int d = 0; d < sl.ndiag; ++d) multi_diag<R, MODE>(a, ops[sl.first + d], base, lt);
+      const int nd = (r == 0 && list0_done) ? 0 : sl.ndiag;     // round 0's list already went into the scalar
+      for (int d = 0; d < nd; ++d) multi_diag<R, MODE>(a, ops[sl.first + d], base, lt);
     }
     multi_slot<R, 0, MODE>(a, ops, rs, base, lt);
     if constexpr (R > 1) multi_slot<R, 1, MODE>(a, ops, rs, base, lt);

@@ -144,7 +144,10 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
         if L >= GEN_TOP_MIN_L and n_pass >= 2 and len(big[-1]) >= MULTI_R:
             top_t = big[-1][:MULTI_R]
             big[-1] = big[-1][MULTI_R:]
-        reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
+        if top_t:      # the last pass has its registers on top: the first (write-only) pass takes bits 6.. itself
+            reg_t = big[0] + [q for b in big[1:] for q in b] + list(dense[k:])
+        else:
+            reg_t = [q for b in big[1:] for q in b] + big[0] + list(dense[k:])
     if not dense and L >= 14:
         # nothing left but the initial product state and its diagonal factors (passes.fold_fresh):
         # libqsv's generator multiplies a factor per AMPLITUDE if it touches one of its register
