@@ -114,27 +114,23 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
             per_pass, n_pass, quota = MULTI_R + dyn_lanes, n_pass_dyn, STATIC_LOW
         else:
             per_pass, n_pass, quota = MULTI_R, n_pass_static, LANE_BITS
-        # The FIRST pass of a circuit is the init-fused, write-only one: with no load latency to
-        # hide behind, a lane gate is exposed there (measured, scripts/dyn_lane_cost.py: +19 % for
-        # three), while a read+write pass takes six for +2 %.  So the first pass gets its register
-        # targets and only as many lane-borne ones as the later passes cannot hold.
-        n_lane_t = min(quota, max(0, nd - per_pass * n_pass))
-        first = nd if n_pass == 1 else max(MULTI_R, nd - ((n_pass - 1) * per_pass + quota))
-        first_big = min(first, per_pass)
-        first_lane = first - first_big
-        later_lane = n_lane_t - first_lane
+        # The FIRST pass of a circuit is the init-fused, write-only one, and its lane gates are nearly
+        # free: every register bit there is a fresh |0> target, so the tile starts as one nonzero
+        # amplitude per lane and libqsv applies the first round's lane gates to that scalar before the
+        # tile exists (k_multi, INIT).  A read+write pass pays ~1 % per lane gate and 3-5 % for
+        # borrowed lane bits.  So the first pass takes every lane-borne target it can -- its own
+        # borrowed ones plus the whole static quota -- and the later passes run lean.
+        first_big = min(nd, per_pass)
+        first_lane = min(quota, nd - first_big)
         big = [list(dense[:first_big])]
         k = first_big
         lane_t += dense[k:k + first_lane]
         k += first_lane
-        for i in range(1, n_pass):
-            if k < nd:
-                pass_heads.append(dense[k])
+        while k < nd:
+            pass_heads.append(dense[k])
             big.append(list(dense[k:k + per_pass]))
             k += per_pass
-            share = later_lane // (n_pass - 1) + (1 if i - 1 < later_lane % (n_pass - 1) else 0)
-            lane_t += dense[k:k + share]
-            k += share
+        n_pass = len(big)
         # Positions: the read+write passes take the low bits (measured at W = 34,
         # scripts/placement_sweep.py: the same pass runs at 5.4 TB/s on bits 6..13 and 5.05 TB/s on
         # 14..21), the write-only first pass -- indifferent to where its targets sit -- the block above
