@@ -104,6 +104,9 @@ def load():
         raise RuntimeError(
             "libqsv.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "
             "or python -m qcmrf_amd.build).  There is no CPU fallback." % LIB_PATH)
+    # the peer-mapped exchange transport shares shards between processes through dmabuf IPC: the
+    # HSA runtime has to be told before it initialises (the pool's boxes export this already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
