@@ -66,9 +66,11 @@ def run(n_cases=300, seed=7, verbose=True):
             else:
                 nc = int(rs.randint(0, 3))
                 ops.append(ir.op_u(qs[0], mat(), ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
-            if rs.rand() < 0.1 and ops[-1].kind != "init":
+            if ops and rs.rand() < 0.1 and ops[-1].kind != "init":
                 ops[-1].new_pass = True
         ops = [o for o in ops if o is not None]
+        if not ops or (len(ops) == 1 and ops[0].kind == "init"):
+            ops.append(ir.op_diag([0], [1.0, 1.0j]))
         opts = {"multi_r": int(rs.choice([5, 5, 5, 4, 6, 3])), "dyn_lanes": int(rs.choice([3, 3, 0, 1, 2])),
                 "lane_map": int(rs.choice([1, 1, 0])), "lane_targets": int(rs.choice([1, 1, 1, 0])),
                 "zero_tracking": int(rs.choice([0, 0, 0, 1])), "init_prod": int(rs.choice([1, 1, 0])),
