@@ -20,6 +20,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_sweeps_$TAG -o r
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sweeps_$TAG -o run -- python3 $ROOT/$CMD2 > $OUT/pmc_fetch_sweeps_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sweeps_$TAG -o run -- python3 $ROOT/$CMD2 > $OUT/pmc_write_sweeps_$TAG.log 2>&1 || exit 1
 echo "sweeps done"
+# ... and at the 34-qubit bench workload
+cd /tmp || exit 1
+CMD3="bench.py --steps 3 --warmup 1 --no-cpu --no-variants --no-fold"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_sweeps34_$TAG -o run -- python3 $ROOT/$CMD3 > $OUT/prof_sweeps34_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sweeps34_$TAG -o run -- python3 $ROOT/$CMD3 > $OUT/pmc_fetch_sweeps34_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sweeps34_$TAG -o run -- python3 $ROOT/$CMD3 > $OUT/pmc_write_sweeps34_$TAG.log 2>&1 || exit 1
+echo "sweeps34 done"
 cd $ROOT
 timeout -k 10 300 python bench.py --gates --steps 20 > $OUT/gates_$TAG.jsonl 2> $OUT/gates_$TAG.err || exit 1
 echo "gates done"
