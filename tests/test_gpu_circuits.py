@@ -35,7 +35,7 @@ def run_state(be, qc, **opts):
     return out, meta
 
 
-@pytest.mark.parametrize("fusion", [0, 1, 2])
+@pytest.mark.parametrize("fusion", [0, 1, 2, 3])
 def test_reference_graphs_amplitudes(be, models, fusion):
     from qcmrf_amd import QCMRF
     for s in ("0.1", "0.5"):
@@ -596,3 +596,24 @@ def test_virtual_shards_default_path_generator(be, P):
     p = cf.probabilities(C, th)
     assert sum(counts.values()) == 4000 and all(p[int(k, 2)] > 0 for k in counts)
     be.run(QCMRF([[0, 1]], [-0.1] * 4), shots=1)
+
+
+@pytest.mark.parametrize("cliques", [
+    [[0, 1, 2], [2, 3, 4], [4, 5, 6], [6, 7, 8]],            # |C| = 3: W = 14, four-qubit factors
+    [[0, 1, 2, 3], [3, 4, 5, 6], [6, 7, 8, 9]],              # |C| = 4: W = 14, five-qubit factors
+    [[0, 1], [1, 2, 3], [3, 4, 5, 6], [6, 7], [7, 8, 9]],    # mixed sizes: W = 16
+])
+def test_larger_cliques_all_paths(be, cliques):
+    """cliques of 3 and 4 variables (run_experiment.py:20 has them at toy width) at a width where
+    the wide kernels run: default path (generator), multiplexed sweeps, gate by gate"""
+    from qcmrf_amd import QCMRF
+    dim = cf.model_shape(cliques)[3]
+    th = random_theta(dim, seed=dim)
+    want = cf.amplitudes(cliques, th)
+    for opts in ({}, {"fold_fresh": False}, {"fusion": 2}, {"fusion": 0}, {"devices": (0, 0)}):
+        amp, meta = run_state(be, QCMRF(cliques, th), **opts)
+        assert np.abs(amp - want).max() < 1e-12, opts
+    kinds = None
+    be.run(QCMRF(cliques, th), shots=0)
+    kinds = be.last_engine.stats()["kinds"]
+    assert set(kinds) == {"init_prod"}, kinds
