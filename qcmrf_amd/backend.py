@@ -74,9 +74,12 @@ def _format_keys(values, counts, num_clbits, creg_sizes):
     w = max(num_clbits, 1)
     values = np.ascontiguousarray(values, dtype=np.uint64)
     if w <= 64:
-        # big-endian bytes -> bits -> ASCII '0'/'1' rows, viewed as fixed-width strings in one go
+        # big-endian bytes -> bits -> UCS4 code points '0'/'1', VIEWED as fixed-width strings: no
+        # per-key conversion at all (an S -> U astype costs more than everything else here together)
         bits = np.unpackbits(values.astype(">u8").view(np.uint8).reshape(-1, 8), axis=1)[:, 64 - w:]
-        keys = np.ascontiguousarray(bits + np.uint8(48)).view("S%d" % w).ravel().astype("U%d" % w).tolist()
+        code = np.empty(bits.shape, dtype=np.uint32)
+        np.add(bits, 48, out=code, casting="unsafe")
+        keys = code.view("<U%d" % w).ravel().tolist()
     else:
         shifts = np.arange(w - 1, -1, -1, dtype=np.uint64)
         chars = (((values[:, None] >> np.minimum(shifts, np.uint64(63))) & np.uint64(1)) * (shifts < 64) + np.uint64(48)).astype(np.uint8)

@@ -155,42 +155,68 @@ for _n in ("ch", "cy", "csx", "crx", "cry", "cu", "cu3"):
 
 
 _MCX_NAMES = ("x", "cx", "ccx", "mcx", "mcx_gray", "c3x", "c4x")
+_MCX_SET = frozenset(_MCX_NAMES)
+
+
+def _flat(definition):
+    """(operations, qubit argument tuples) of a definition's instructions"""
+    data = definition.data
+    try:
+        return [ci.operation for ci in data], [ci.qubits for ci in data]
+    except AttributeError:                                   # legacy (op, qargs, cargs) tuples
+        return [ci[0] for ci in data], [ci[1] for ci in data]
+
+
+def _and_key(definition):
+    """Structural signature of a small flat definition -- gate names, qubit positions, control
+    state of the middle gate -- or None if it cannot be X..X . MCX . X..X.  Hot: a 34-qubit QCMRF
+    circuit has 304 AND instances (two per clique state, QCMRF.py:225,227) but only 4 distinct
+    signatures; everything beyond reading the signature off the object is memoised on it."""
+    n = len(definition.data)
+    if not n & 1 or n > 33 or getattr(definition, "global_phase", 0):
+        return None
+    qs = getattr(definition, "qubits", None)
+    if qs is None:
+        return None
+    ops, qargs = _flat(definition)
+    if [o for o in ops if getattr(o, "condition", None) is not None]:
+        return None
+    return (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]),
+            tuple([qs.index(q) for qa in qargs for q in qa]), getattr(ops[n >> 1], "ctrl_state", None))
+
+
+_SHAPES = {}
+
+
+def _shape_of_key(key):
+    """(ctrls, vals, target) for the signature of an X..X . MCX . X..X definition with the same X
+    set on both sides, else None (memoised: a pure function of the signature)"""
+    try:
+        return _SHAPES[key]
+    except KeyError:
+        pass
+    names, lens, pos, state = key
+    n = len(names)
+    f = n >> 1
+    res = None
+    if names[f] in _MCX_SET and all(nm == "x" and ln == 1 for nm, ln in zip(names[:f] + names[f + 1:], lens[:f] + lens[f + 1:])):
+        head, mid, tail = pos[:f], pos[f:f + lens[f]], pos[f + lens[f]:]
+        ctrls, tgt = list(mid[:-1]), mid[-1]
+        vals = [1] * len(ctrls) if state is None else [(int(state) >> i) & 1 for i in range(len(ctrls))]
+        if (sorted(head) == sorted(tail) and len(set(head)) == f and len(set(mid)) == len(mid)
+                and tgt not in head and all(x in ctrls for x in head)):
+            res = (ctrls, [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)], tgt)
+    if len(_SHAPES) > 4096:
+        _SHAPES.clear()
+    _SHAPES[key] = res
+    return res
 
 
 def _conjugated_mcx_shape(definition):
     """(ctrls, vals, target) in the definition's own qubit numbering if it is X..X . MCX . X..X
     with the same X set on both sides, else None."""
-    data = definition.data
-    n = len(data)
-    if n < 1 or n % 2 == 0 or n > 33 or getattr(definition, "global_phase", 0):
-        return None
-    f = n // 2
-    mid, mq, _ = _unpack(data[f])
-    if mid.name not in _MCX_NAMES or getattr(mid, "condition", None) is not None:
-        return None
-    qs = getattr(definition, "qubits", None)
-    if qs is None:
-        return None
-    qi = {id(b): i for i, b in enumerate(qs)}
-    mq = [qi[id(b)] for b in mq]
-    ctrls, tgt = mq[:-1], mq[-1]
-    vals = _ctrl_vals(mid, len(ctrls))
-    if f == 0:
-        return ctrls, vals, tgt
-    head, tail = [], []
-    for k in range(f):
-        a, aq, _ = _unpack(data[k])
-        b, bq, _ = _unpack(data[n - 1 - k])
-        if a.name != "x" or b.name != "x" or len(aq) != 1 or len(bq) != 1:
-            return None
-        head.append(qi[id(aq[0])])
-        tail.append(qi[id(bq[0])])
-    if sorted(head) != sorted(tail) or len(set(head)) != f:
-        return None
-    if tgt in head or any(x not in ctrls for x in head):
-        return None
-    vals = [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)]
-    return ctrls, vals, tgt
+    key = _and_key(definition)
+    return None if key is None else _shape_of_key(key)
 
 
 _PHASE_MASKS = {}
@@ -211,11 +237,71 @@ def _phase_mask(k, y):
     return m
 
 
+_BLOCKS = {}
+
+
+def _block_of_key(key):
+    """(ctrls, scratch, other, mask matrix) for the signature of a definition made of nothing but
+    ``AND . cp . AND`` triples on one (controls, scratch, other) set, else None (memoised)"""
+    try:
+        return _BLOCKS[key]
+    except KeyError:
+        pass
+    names, lens, pos, and_keys = key
+    n = len(names)
+    res = None
+    starts = [0]
+    for ln in lens:
+        starts.append(starts[-1] + ln)
+    wires = None
+    ys = []
+    ok = True
+    for k in range(0, n, 3):
+        if names[k + 1] not in ("cp", "cu1") or lens[k + 1] != 2:
+            ok = False
+            break
+        sa, sb = _shape_of_key(and_keys[k]), _shape_of_key(and_keys[k + 2])
+        if sa is None or sb is None or sa[1] != sb[1]:
+            ok = False
+            break
+        la, lb = pos[starts[k]:starts[k + 1]], pos[starts[k + 2]:starts[k + 3]]
+        if len(la) <= max(sa[0] + [sa[2]]) or len(lb) <= max(sb[0] + [sb[2]]):
+            ok = False
+            break
+        ctrls, tgt = [la[c] for c in sa[0]], la[sa[2]]
+        if ctrls != [lb[c] for c in sb[0]] or tgt != lb[sb[2]]:
+            ok = False
+            break
+        p0, p1 = pos[starts[k + 1]:starts[k + 2]]
+        other = p0 if p1 == tgt else p1 if p0 == tgt else -1
+        if other < 0 or other == tgt or other in ctrls:
+            ok = False
+            break
+        if wires is None:
+            wires = (ctrls, tgt, other)
+        elif wires != (ctrls, tgt, other):
+            ok = False
+            break
+        ys.append(sum(v << e for e, v in enumerate(sa[1])))
+    if ok and wires is not None:
+        kk = len(wires[0])
+        res = (wires[0], wires[1], wires[2], np.stack([_phase_mask(kk, y) for y in ys], axis=1))
+    if len(_BLOCKS) > 1024:
+        _BLOCKS.clear()
+    _BLOCKS[key] = res
+    return res
+
+
 def _emit_phase_block(definition, qmap, out):
     """A definition that is nothing but ``AND . cp . AND`` triples on one (controls, scratch, other)
     set -- the reference's ``cU_C`` and its inverse (QCMRF.py:218-228,234) -- is a diagonal:
     each triple puts e^{i lam} on { other = 1 and scratch xor [controls == y] = 1 }.  Emit that one
-    table instead of 3 x 2^|C| gates (exact: MCX . D . MCX with D diagonal is diagonal)."""
+    table instead of 3 x 2^|C| gates (exact: MCX . D . MCX with D diagonal is diagonal).
+
+    The whole block is recognised in ONE step: its structural signature (names, qubit positions,
+    the signatures of its AND definitions) is read off the objects and looked up; only the phase
+    angles are per-instance.  The signature is content, not object identity: nothing is cached on
+    or about the caller's circuit."""
     data = definition.data
     n = len(data)
     if n < 3 or n % 3 or getattr(definition, "global_phase", 0):
@@ -223,58 +309,37 @@ def _emit_phase_block(definition, qmap, out):
     qs = getattr(definition, "qubits", None)
     if qs is None:
         return False
+    ops, qargs = _flat(definition)
+    for p in ops[1::3]:
+        if getattr(p, "condition", None) is not None or getattr(p, "ctrl_state", None) not in (None, 1):
+            return False
+    and_keys = []
+    for k, o in enumerate(ops):
+        if k % 3 == 1:
+            and_keys.append(None)
+            continue
+        d = getattr(o, "definition", None)
+        if d is None or getattr(o, "condition", None) is not None:
+            return False
+        ak = _and_key(d)
+        if ak is None:
+            return False
+        and_keys.append(ak)
     qi = {id(b): i for i, b in enumerate(qs)}
-    key = None
-    terms = []
-    n_src = 0
-    for k in range(0, n, 3):
-        (a, aq, _), (p, pq, _), (b, bq, _) = _unpack(data[k]), _unpack(data[k + 1]), _unpack(data[k + 2])
-        if p.name not in ("cp", "cu1") or getattr(p, "condition", None) is not None or getattr(p, "ctrl_state", None) not in (None, 1):
-            return False
-        da, db = getattr(a, "definition", None), getattr(b, "definition", None)
-        if da is None or db is None:
-            return False
-        sa = _conjugated_mcx_shape(da)
-        if sa is None:
-            return False
-        sb = sa if db is da else _conjugated_mcx_shape(db)
-        if sb is None:
-            return False
-        # map the AND's local qubits to this definition's qubits
-        la = [qi[id(x)] for x in aq]
-        lb = [qi[id(x)] for x in bq]
-        ga = ([la[c] for c in sa[0]], sa[1], la[sa[2]])
-        gb = ([lb[c] for c in sb[0]], sb[1], lb[sb[2]])
-        if ga != gb:
-            return False
-        pl = [qi[id(x)] for x in pq]
-        ctrls, vals, tgt = ga
-        if tgt not in pl or len(pl) != 2:
-            return False
-        other = pl[0] if pl[1] == tgt else pl[1]
-        if other in ctrls or other == tgt:
-            return False
-        if key is None:
-            key = (tuple(ctrls), tgt, other)
-        elif key != (tuple(ctrls), tgt, other):
-            return False
-        terms.append((vals, _fparams(p)[0]))
-        n_src += len(da.data) + len(db.data) + 1
-    ctrls, tgt, other = key
-    qs = list(ctrls) + [tgt, other]
-    glob = [qmap[x] for x in qs]
+    key = (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]),
+           tuple([qi[id(q)] for qa in qargs for q in qa]), tuple(and_keys))
+    blk = _block_of_key(key)
+    if blk is None:
+        return False
+    ctrls, tgt, other, M = blk
+    glob = [qmap[x] for x in ctrls]
+    glob.append(qmap[tgt])
+    glob.append(qmap[other])
     if out._measured and out._measured.intersection(glob):
         return False
-    k = len(ctrls)
-    ang = None
-    for vals, lam in terms:
-        y = 0
-        for e, v in enumerate(vals):
-            y |= v << e
-        t = lam * _phase_mask(k, y)
-        ang = t if ang is None else ang + t
+    ang = M @ np.array([_fparams(p)[0] for p in ops[1::3]], dtype=np.float64)
     out.ops.append(ir.Op("diag", qubits=tuple(glob), table=np.exp(1j * ang)))
-    out.n_source_ops += n_src
+    out.n_source_ops += n // 3 + sum([len(ops[k].definition.data) for k in range(0, n, 3)]) + sum([len(ops[k].definition.data) for k in range(2, n, 3)])
     return True
 
 

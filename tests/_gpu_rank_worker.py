@@ -23,10 +23,64 @@ from qcmrf_amd.backend import QsvBackend             # noqa: E402
 from qcmrf_amd.comm import TorchDistComm             # noqa: E402
 
 
+def config4(comm, out_path):
+    """BASELINE config 4 (W = 31, 32 GiB) sharded over the ranks: 16 GiB (2 ranks) / 8 GiB (4 ranks)
+    shards, reference layout with full-width sweeps so that the planner must exchange half-shards
+    (peer-mapped transport here: the ranks share the box's one GPU).  Too wide to gather: every
+    rank checks slices of ITS shard against the closed form; masses and counts are merged."""
+    rank, world = comm.rank, comm.world
+    name, C = workloads.baseline_config(3)
+    n, m, W, dim = cf.model_shape(C)
+    th = workloads.theta_halfnorm(dim)
+    L = W - (world.bit_length() - 1)
+    results = {}
+    for layout, fold in (("reference", False), ("auto", False), ("auto", True)):
+        be = QsvBackend(comm=comm, device=0, layout=layout, fold_fresh=fold)
+        res = be.run(QCMRF(C, th), shots=4096, seed_simulator=1984).result()
+        meta = res.metadata(0)
+        eng = be.last_engine
+        lay = meta["layout"]
+        rs = np.random.RandomState(rank)
+        err = 0.0
+        starts = [0, (1 << L) - 4096] + [int(x) for x in rs.randint(0, (1 << L) - 4096, size=8)]
+        for st0 in starts:
+            g0 = (rank << L) + st0
+            got = eng.amplitudes(g0, 4096)
+            pidx = np.arange(g0, g0 + 4096, dtype=np.uint64)
+            lidx = np.zeros_like(pidx)
+            for q, pos in enumerate(lay):
+                lidx |= ((pidx >> np.uint64(pos)) & np.uint64(1)) << np.uint64(q)
+            err = max(err, float(np.abs(got - cf.amplitudes_at(C, th, lidx)).max()))
+        errs = comm.allgather(err)
+        masses = comm.allgather(eng.norm())
+        st = eng.stats()
+        xs = comm.allgather(int(st["exchanges"]))
+        counts = res.get_counts()
+        if rank == 0:
+            p, Z = cf.gibbs_pmf(C, th)
+            ok = sum(v for k, v in counts.items() if int(k, 2) < 2 ** n)
+            pr = cf.probabilities_at(C, th, np.array([int(k, 2) for k in counts], dtype=np.uint64))
+            results["%s/%s" % (layout, "fold" if fold else "sweeps")] = {
+                "err": max(errs), "norm": float(sum(masses)), "n_exchanges": meta["n_exchanges"], "engine_exchanges": xs,
+                "transport": getattr(eng, "transport", None), "shots": int(sum(counts.values())),
+                "outside_support": int((pr <= 0).sum()), "success": ok / 4096.0, "delta": float(Z / 2 ** n),
+                "evolve_ms": meta["time_evolve"] * 1e3}
+        comm.barrier()
+        be.close()
+    if rank == 0:
+        json.dump(results, open(out_path, "w"))
+    comm.barrier()
+
+
 def main():
     out_path = sys.argv[1]
     comm = TorchDistComm("gloo")
     rank, world = comm.rank, comm.world
+    if len(sys.argv) > 2 and sys.argv[2] == "config4":
+        config4(comm, out_path)
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        return
     C = workloads.chain(8)                            # n = 8, m = 7, W = 16: L = 15 / 14 local qubits
     th = workloads.theta_halfnorm(workloads.dimension(C))
     want = cf.amplitudes(C, th)

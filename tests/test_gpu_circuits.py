@@ -200,6 +200,28 @@ def test_full_size_w28_properties(be):
     _full_size_properties(be, C, fusion=1, engine_options={"zero_tracking": 0})
 
 
+@pytest.mark.parametrize("P", [2, 4])
+def test_full_size_w31_config4(be, P):
+    """BASELINE config 4 (random graph G(10,20), W = 31, 32 GiB state) on 2 then 4 shards of one
+    device: 16 / 8 GiB shards, so the shard-bit exchanges move real 8 / 4 GiB half-shards.
+    layout='reference' keeps the ancillas -- the dense targets -- on the top bits (QCMRF.py:231-236,
+    qubit n+1+ii), i.e. ON the shard bits: with fold_fresh off their multiplexers must sweep, so the
+    planner has to exchange; layout='auto' shards by variable qubits and needs none."""
+    from qcmrf_amd import workloads
+    name, C = workloads.baseline_config(3)
+    assert cf.model_shape(C) == (10, 20, 31, 80)
+    devs = (0,) * P
+    meta = _full_size_properties(be, C, devices=devs)                                   # default path: generator per shard
+    assert meta["n_shards"] == P and meta["n_exchanges"] == 0
+    meta = _full_size_properties(be, C, devices=devs, fold_fresh=False)                 # sweeps, exchange-free layout
+    assert meta["n_exchanges"] == 0
+    meta = _full_size_properties(be, C, devices=devs, layout="reference", fold_fresh=False)
+    assert meta["n_exchanges"] >= 1
+    st = be.last_engine.stats()
+    assert st["exchanges"] == meta["n_exchanges"] and "exchange" in st["kinds"]
+    be.run(__import__("qcmrf_amd").QCMRF([[0, 1]], [-0.1] * 4), shots=1, devices=(0,))  # frees the 32 GiB
+
+
 def test_full_size_w32_64bit_addressing(be):
     """a 64 GiB shard (the size class of the 8-GPU config's 32 GiB shards and beyond): every byte
     offset above 2^32 and every index above 2^31 is live here"""

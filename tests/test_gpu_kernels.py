@@ -172,6 +172,48 @@ def test_swap_layout_local(lib):
     assert np.array_equal(got, want)
 
 
+def test_direct_shard_bit_swap_after_exec_drops_the_cached_tile_sums(lib):
+    """qsv_exec leaves per-tile |amp|^2 sums for sampling; a qsv_swap_layout across a shard bit
+    issued directly through the C ABI afterwards (Engine.swap_layout) moves amplitudes between
+    the shards without a launch on every one of them -- norm and sample must then see the NEW
+    state, not the sums and tile order of the old one (2 virtual shards, vs the numpy engine)."""
+    from qcmrf_amd import ir, program
+    from oracle.sharded_numpy import NumpyEngine
+    W, P = 16, 2
+    rs = np.random.RandomState(3)
+    # an unevenly weighted state: shard 0 and shard 1 carry different mass before and after the swap
+    ops = [ir.op_init((1 << W) - 1 - (1 << 9))]
+    for t, a in ((9, 0.4), (6, 1.1), (7, 0.3)):
+        ops.append(ir.op_mux([W - 1, 2], t, np.array([[[np.cos(a * k), -1j * np.sin(a * k)], [-1j * np.sin(a * k), np.cos(a * k)]]
+                                                       for k in (0.5, 1.0, 1.7, 2.9)])))
+    rec, data = program.encode(ops)
+    ref = NumpyEngine(W, P)
+    ref.exec(rec, data)
+    with lib.Engine(W, devices=(0,) * P) as e:
+        e.exec(rec, data)
+        m0 = e.norm()
+        assert abs(m0 - 1.0) < 1e-12
+        e.sample(2000, 5)                                    # fetches and caches the tile sums of the pre-swap state
+        e.swap_layout([W - 1], [9])                         # shard bit <-> local bit, straight through the C ABI
+        ref.swap_layout([W - 1], [9])
+        want = ref.amplitudes()
+        assert np.abs(e.amplitudes() - want).max() < 1e-13
+        assert abs(e.norm() - 1.0) < 1e-12
+        p = np.abs(want) ** 2
+        shots = 100000
+        idx = e.sample(shots, 5)
+        obs = np.bincount(idx.astype(np.int64), minlength=p.size)
+        assert obs[p == 0].sum() == 0                        # a stale tile order lands on unpopulated indices
+        pb, ob = p.reshape(-1, 64).sum(1), obs.reshape(-1, 64).sum(1)
+        keep = pb * shots > 5
+        chi = ((ob[keep] - pb[keep] * shots) ** 2 / (pb[keep] * shots)).sum() / (keep.sum() - 1)
+        assert 0.8 < chi < 1.2, chi
+        # per-shard mass after the swap (the numbers a multi-rank sampling merge would use)
+        half = p.size // 2
+        got = e.probabilities([W - 1])
+        assert np.abs(got - np.array([p[:half].sum(), p[half:].sum()])).max() < 1e-12
+
+
 def test_probabilities_norm_and_conditional(lib):
     n = 12
     ref = rand_state(n, 23)
