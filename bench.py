@@ -21,9 +21,18 @@ configs[1] (20 qubits), same step definition, not part of ``value``.
 theta = -halfnorm.rvs(scale=0.5), seed 1984; 4096 shots; seed_simulator 1984.
 
 The JSON line carries ``roofline`` (dominant kernel, HIP-event timed on its launch stream over
-the timed steps, algorithmic bytes of SURVEY.md 8(d)) and, at N=1, ``cpu_baseline`` (the plain-C
-oracle -- a port, Aer itself is not installable offline -- on a bounded sample of the same
-workload).  ``--gates`` runs the gate-apply micro-benchmark instead (one JSON object per gate kind).
+the timed steps, algorithmic bytes of SURVEY.md 8(d)) and, at N=1, ``roofline_gate_sweeps_28q``
+(BASELINE configs[2], the 28-qubit roofline config, with every fused gate SWEPT over the vector:
+the read+write ``k_multi`` pass is the "gate-apply sweep" of the north star), ``gate_microbench_28q``
+(one kernel per gate kind on a 28-qubit state: min / median / worst fraction of peak) and
+``cpu_baseline`` (the plain-C oracle -- a port, Aer itself is not installable offline -- on a
+bounded sample of the same workload).  At N>1 it also carries ``exchange_legs``: the same circuit in
+the reference layout (ancillas on the shard bits), which forces shard-bit exchanges over RCCL and
+over the peer-mapped transport -- so the RCCL communicator really spans the N ranks
+(``rccl_ranks``).  ``--gates`` runs only the gate-apply micro-benchmark (one JSON object per gate kind).
+
+Host processes rendezvous through qcmrf_amd.comm (standard library sockets; the launcher's RANK /
+WORLD_SIZE / MASTER_* environment): bench.py imports no torch.
 """
 from __future__ import annotations
 
@@ -64,6 +73,8 @@ def parse():
     ap.add_argument("--no-fold", action="store_true",
                     help="fold_fresh off: every fused gate is applied as a sweep of the full vector (k_multi passes)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
+    ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the reference-layout legs (RCCL / peer-mapped shard-bit exchanges)")
+    ap.add_argument("--exchange-deadline", type=float, default=240.0, help="seconds one exchange leg may take before it is abandoned")
     return ap.parse_args()
 
 
@@ -145,11 +156,11 @@ def cpu_baseline(cliques, theta, shots, budget_s):
 
 
 # --------------------------------------------------------------------------------------------
-def gate_microbench(args):
+def gate_microbench(args, W=None, quiet=False):
     """dense 1q at every target, X, CX, CCX(+-flags), CP, 3q diagonal, mux-RX, 5q dense on a
     W-qubit state: HIP-event time per launch -> GB/s against the algorithmic byte model."""
     from qcmrf_amd import _lib
-    W = args.qubits or 28
+    W = W or args.qubits or 28
     reps = max(args.steps, 5)
     rs = np.random.RandomState(0)
 
@@ -194,17 +205,18 @@ def gate_microbench(args):
         ms = eng.timer_end() / reps
         gbps = nbytes / ms / 1e6
         out.append({"gate": name, "ms": ms, "GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS})
-        print(json.dumps(out[-1]), flush=True)
+        if not quiet:
+            print(json.dumps(out[-1]), flush=True)
     eng.close()
     return out
 
 
 # --------------------------------------------------------------------------------------------
-def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=()):
+def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=(), **run_opts):
     """W warm-up runs, then exactly `steps` runs bracketed by barrier + device sync on both sides;
     elapsed = max over ranks.  Returns the per-kernel HIP-event aggregation as well."""
     for i in range(warmup):
-        backend.run(qc, shots=shots, seed_simulator=seed0 + i).result()
+        backend.run(qc, shots=shots, seed_simulator=seed0 + i, **run_opts).result()
     for o in options:
         k, v = o.split("=")
         backend.last_engine.set_option(k, int(v))
@@ -214,7 +226,7 @@ def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=()):
     agg = {}
     t = {"compile": 0.0, "evolve": 0.0, "sample": 0.0}
     for i in range(steps):
-        res = backend.run(qc, shots=shots, seed_simulator=seed0 + warmup + i, profile=True).result()
+        res = backend.run(qc, shots=shots, seed_simulator=seed0 + warmup + i, profile=True, **run_opts).result()
         meta = res.metadata(0)
         for k in t:
             t[k] += meta["time_" + k]
@@ -239,12 +251,83 @@ def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=()):
                          "avg_launch_ms": d["ms"] / d["launches"], "rank": 0}}
 
 
+PMC_FILE = "profiles/pmc_traffic.json"
+
+
 def pmc_traffic(dom, W):
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """HBM bytes per launch from the PMC counters -- NOT measured by this run: read from the committed
+    summary of a separate rocprofv3 --pmc run of this same command (scripts/profile_round.sh), and
+    labelled as such in the JSON line (``traffic`` itself stays null)."""
     try:
-        return json.load(open(tfile)).get("k_" + dom, {}).get("hbm_bytes_per_launch_W%d" % W)
+        v = json.load(open(os.path.join(ROOT, PMC_FILE))).get("k_" + dom, {}).get("hbm_bytes_per_launch_W%d" % W)
     except Exception:
-        return None
+        v = None
+    return None if v is None else {"hbm_bytes_per_launch": v, "file": PMC_FILE,
+                                   "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run"}
+
+
+def run_exchange_legs(args, comm, qc, device, world):
+    """reference layout + fold_fresh off on all ranks, once per transport.  Returns a dict (rank 0's
+    view); a leg that raises is recorded; a leg that does not come back within the deadline makes
+    the watchdog print what has been measured so far and end the process (every rank has one)."""
+    import threading
+    from qcmrf_amd.backend import QsvBackend
+    out = {"rccl_ranks": 0, "layout": "reference (ancillas = dense targets on the shard bits)", "fold_fresh": False}
+    for transport in ("rccl", "p2p"):
+        done = threading.Event()
+        leg = {}
+
+        def work(transport=transport, leg=leg, done=done):
+            be = None
+            try:
+                be = QsvBackend(fusion=args.fusion, layout="reference", comm=comm, device=device, fold_fresh=False,
+                                exchange=transport)
+                be.run(qc, shots=args.shots, seed_simulator=11).result()               # bootstrap + warm-up
+                comm.barrier()
+                t0 = time.perf_counter()
+                n = 2
+                for i in range(n):
+                    r = be.run(qc, shots=args.shots, seed_simulator=12 + i, profile=True).result()
+                be.last_engine.sync()
+                comm.barrier()
+                dt = max(comm.allgather(time.perf_counter() - t0))
+                m = r.metadata(0)
+                st = m["stats"]
+                ex = st["kinds"].get("exchange", {})
+                leg.update({"transport": getattr(be.last_engine, "transport", None), "ranks": world,
+                            "ms_per_step": dt / n * 1e3, "exchanges_per_step": m["n_exchanges"],
+                            "exchange_ms_each": ex.get("ms", 0.0) / max(1, ex.get("launches", 1)),
+                            "exchange_bytes_sent_per_rank_per_step": st["exchange_bytes"],
+                            "evolve_ms": m["time_evolve"] * 1e3})
+            except Exception as e:                                                       # noqa: BLE001
+                leg["error"] = repr(e)[:300]
+            finally:
+                try:
+                    if be is not None:
+                        be.close()
+                except Exception:                                                        # noqa: BLE001
+                    pass
+                done.set()
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        if not done.wait(args.exchange_deadline):
+            leg["error"] = "no result within %.0f s: abandoned" % args.exchange_deadline
+            out[transport] = leg
+            out["abandoned"] = transport
+            return out            # the worker thread may still sit in a device call: the caller prints and exits
+        try:
+            oks = comm.allgather("error" not in leg)
+        except Exception as e:                                                           # noqa: BLE001
+            leg.setdefault("error", "a peer left during the leg: %r" % (e,))
+            out[transport] = leg
+            out["abandoned"] = transport
+            return out
+        if not all(oks):
+            leg.setdefault("error", "failed on rank(s) %s" % [i for i, ok in enumerate(oks) if not ok])
+        out[transport] = leg
+        if transport == "rccl" and "error" not in leg and leg.get("transport") == "rccl":
+            out["rccl_ranks"] = world
+    return out
 
 
 def main():
@@ -260,7 +343,7 @@ def main():
     # the HIP library first: it must be /opt/rocm's runtime that ends up in the process
     from qcmrf_amd import _lib, QCMRF
     from qcmrf_amd.backend import QsvBackend
-    from qcmrf_amd.comm import SingleProcess, TorchDistComm
+    from qcmrf_amd import comm as qcomm
     from qcmrf_amd import workloads as wl
     _lib.load()
     n_dev = _lib.device_count()          # initialises /opt/rocm's HIP runtime before torch brings its own copy in
@@ -269,7 +352,7 @@ def main():
         gate_microbench(args)
         return
 
-    comm = TorchDistComm("gloo", timeout_s=600) if world > 1 else SingleProcess()
+    comm = qcomm.from_environment(timeout_s=600)
     device = local_rank % max(1, n_dev)
     hbm_total = comm.bcast(_lib.device_memory(device)[0] if rank == 0 else None)    # FREE bytes on rank 0's device
     name, cliques, theta = workload(args, hbm_total)
@@ -339,7 +422,6 @@ def main():
             assert len(rb.get_counts()) == nb
             variants["batch of %d circuits in one run() call (host compile overlapped with device work)" % nb] = {
                 "shots_per_s": args.shots * nb / dt, "ms_per_step": dt / nb * 1e3}
-        backend.run(qc, shots=16, engine_options={"zero_tracking": 0})
 
     # N = 1: the other single-GPU configs of BASELINE.json, same step definition (not part of `value`)
     other = {}
@@ -349,14 +431,58 @@ def main():
             oq = QCMRF(oc, wl.theta_halfnorm(wl.dimension(oc)))
             lg = timed_leg(backend, comm, oq, args.shots, max(args.steps, 10), 2)
             rf = lg["roofline"]
-            rf["traffic"] = pmc_traffic(lg["dom"], oq.num_qubits)
+            rf["traffic_from_profiles"] = pmc_traffic(lg["dom"], oq.num_qubits)
             other[oname] = {"shots_per_s": args.shots * max(args.steps, 10) / lg["elapsed"],
                             "ms_per_step": lg["elapsed"] / max(args.steps, 10) * 1e3,
                             "breakdown_ms": lg["breakdown_ms"], "kernels": lg["kernels"], "roofline": rf}
 
+    # N = 1: the north-star roofline, measured in THIS run: BASELINE configs[2] (28 qubits) with every
+    # fused gate swept over the vector (fold_fresh off) -- the read+write k_multi pass is the
+    # "gate-apply sweep"; and one kernel per gate kind on a 28-qubit state (--gates in brief)
+    sweeps28, gates28 = None, None
+    if world == 1 and not args.no_variants and not (args.qubits or args.config or args.virtual_shards):
+        oname, oc = wl.baseline_config(2)
+        oq = QCMRF(oc, wl.theta_halfnorm(wl.dimension(oc)))
+        nst = max(args.steps, 20)
+        lg = timed_leg(backend, comm, oq, args.shots, nst, 3, fold_fresh=False)
+        km, ki = lg["agg"].get("multi"), lg["agg"].get("multi_init")
+        if km and km["ms"] > 0:
+            gb = km["bytes"] / km["ms"] / 1e6
+            sweeps28 = {"bound": "hbm", "kernel": "k_multi<5,false,2> (read+write pass over the shard: the gates of one pass "
+                                                  "are applied in registers between one load and one store of every amplitude)",
+                        "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
+                        "traffic": None, "traffic_from_profiles": pmc_traffic("multi", oq.num_qubits),
+                        "algorithmic_bytes_per_launch": km["bytes"] / km["launches"], "avg_launch_ms": km["ms"] / km["launches"],
+                        "launches_per_step": km["launches"] / nst, "steps": nst, "workload": oname,
+                        "gates_per_step_on_device": lg["meta"]["n_device_ops"] - 1,
+                        "ms_per_step": lg["elapsed"] / nst * 1e3, "shots_per_s": args.shots * nst / lg["elapsed"],
+                        "breakdown_ms": lg["breakdown_ms"], "note": "fold_fresh=False; not part of `value`"}
+            if ki and ki["ms"] > 0:
+                sweeps28["init_fused_pass"] = {"kernel": "k_multi<5,true,2> (write-only first pass)", "avg_launch_ms": ki["ms"] / ki["launches"],
+                                               "achieved": ki["bytes"] / ki["ms"] / 1e6, "frac": ki["bytes"] / ki["ms"] / 1e6 / HBM_PEAK_GBPS,
+                                               "algorithmic_bytes_per_launch": ki["bytes"] / ki["launches"]}
+        backend.close()
+        g = gate_microbench(args, W=28, quiet=True)
+        fr = sorted((x["frac_of_8TBps"], x["gate"]) for x in g)
+        gates28 = {"qubits": 28, "n_cases": len(g), "min_frac": fr[0][0], "worst": fr[0][1], "median_frac": fr[len(fr) // 2][0],
+                   "max_frac": fr[-1][0], "best": fr[-1][1], "n_below_0.60": sum(1 for f, _ in fr if f < 0.60),
+                   "frac_by_gate": {x["gate"]: round(x["frac_of_8TBps"], 3) for x in g},
+                   "note": "one dedicated kernel per gate, HIP-event time over %d launches each, algorithmic bytes of SURVEY.md 8(d); "
+                           "controlled gates are charged the control-satisfied subspace only" % max(args.steps, 5)}
+
+    # N > 1: the same circuit in the reference layout (qubit q on bit q: the ancillas, i.e. the dense
+    # targets, sit on the shard bits -- QCMRF.py:231-236) with full-width sweeps, so the planner has
+    # to exchange shard bits: once over RCCL (the communicator then really spans the N ranks) and
+    # once over the peer-mapped transport.  Never part of `value`.  A watchdog keeps a transport
+    # that hangs from taking the already measured line down with it.
+    exchange_legs = None
+    if world > 1 and not args.no_exchange_leg:
+        backend.close()                       # its numbers are in; the legs allocate their own shards
+        exchange_legs = run_exchange_legs(args, comm, qc, device, world)
+
     if rank == 0:
         roof = main_leg["roofline"]
-        roof["traffic"] = pmc_traffic(main_leg["dom"], W)
+        roof["traffic_from_profiles"] = pmc_traffic(main_leg["dom"], W)
         line = {
             "metric": "shots/sec, n-qubit QCMRF circuit (fp64 statevector, ingest+evolve+sample)",
             "value": args.shots * args.steps / elapsed, "unit": "shots/s",
@@ -384,19 +510,30 @@ def main():
             if km and km.get("GBps"):
                 line["roofline_gate_sweeps"] = {
                     "bound": "hbm", "kernel": "k_multi", "achieved": km["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": km["GBps"] / HBM_PEAK_GBPS, "traffic": pmc_traffic("multi", W),
+                    "frac": km["GBps"] / HBM_PEAK_GBPS, "traffic": None, "traffic_from_profiles": pmc_traffic("multi", W),
                     "avg_launch_ms": km["avg_ms"], "launches_per_step": km["launches_per_step"],
                     "shots_per_s": v["shots_per_s"], "ms_per_step": v["ms_per_step"],
                     "note": "variant, not part of `value`: fold_fresh=False"}
+        if sweeps28:
+            line["roofline_gate_sweeps_28q"] = sweeps28
+        if gates28:
+            line["gate_microbench_28q"] = gates28
+        if exchange_legs is not None:
+            line["exchange_legs"] = exchange_legs
+            line["rccl_ranks"] = exchange_legs.get("rccl_ranks", 0)
         if other:
             line["other_configs"] = other
         if args.gpus == 1 and not args.no_cpu:
             backend.close()
             line["cpu_baseline"] = cpu_baseline(cliques, theta, args.shots, args.cpu_seconds)
         print(json.dumps(line), flush=True)
+    if exchange_legs is not None and exchange_legs.get("abandoned"):
+        sys.stdout.flush()
+        os._exit(0)               # a transport is stuck in a device call on some rank: nothing left to wait for
     backend.close()
     if world > 1:
         comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -113,6 +113,12 @@ int qsv_ipc_attach(qsv_handle* h, const uint8_t* handles /* world x QSV_IPC_HAND
  * with a single GPU, where RCCL refuses two ranks on one device.  0 on success. */
 int qsv_rccl_selftest(int device_id, uint64_t n_doubles);
 
+/* Diagnostic: the RCCL side of a BATCHED exchange (several shard bits at once = an all-to-all inside a
+ * group of shards) on a 1-rank communicator with rank 0 as its own peers: staging buffers, the
+ * two-stream double-buffered pack / grouped send+recv / unpack pipeline in chunks of 2^chunk_log2
+ * amplitudes over a 2^n_qubits shard, verified element by element.  0 on success. */
+int qsv_rccl_exchange_selftest(int device_id, int n_qubits, int chunk_log2);
+
 int qsv_destroy(qsv_handle* h);
 int qsv_sync(qsv_handle* h);
 
@@ -158,8 +164,13 @@ int qsv_apply_mux_1q(qsv_handle* h, int k, const int* ctrls, int t, const double
 int qsv_apply_kq(qsv_handle* h, int k, const int* qubits, const double* u);
 
 /* physically swap the amplitude-index positions a[i] <-> b[i].  Both local: a permutation
- * sweep.  One of them a shard bit: the pairwise half-shard exchange (device copy for
- * virtual shards, peer copy between devices of one process, RCCL send/recv between ranks). */
+ * sweep.  One of them a shard bit: the pairwise half-shard exchange (in-place swap kernel for
+ * virtual shards and peer-mapped ranks, peer copy between devices of one process, RCCL
+ * send/recv between ranks).  Several such pairs on distinct qubits in ONE call are executed as
+ * one batched exchange: an all-to-all inside every group of 2^k shards (each shard sends 1/2^k
+ * of itself to each of its 2^k - 1 partners, all links busy at once) instead of k sequential
+ * half-shard exchanges.  The RCCL path is chunked and double buffered (pack / unpack on a second
+ * stream while the neighbouring chunk is on the wire). */
 int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const int* b);
 
 /* ---- measurement (QCMRF.py:239,243; shots of run_experiment.py:56) -------------------- */
@@ -170,6 +181,18 @@ int qsv_swap_layout(qsv_handle* h, int npairs, const int* a, const int* b);
 int qsv_probabilities(qsv_handle* h, const int* qubits, int k, double* out);
 int qsv_probabilities_cond(qsv_handle* h, const int* qubits, int k,
                            uint64_t fix_mask, uint64_t fix_val, double* out);
+
+/* expectation of a real DIAGONAL observable on the resident state: table has 2^k doubles, indexed
+ * like qsv_apply_diag's (k <= 26; qubits may include shard bits).  Only amplitudes whose global
+ * index g has (g & fix_mask) == fix_val contribute:
+ *     out[0] = sum |amp[g]|^2 table[j(g)]      out[1] = sum |amp[g]|^2      (both over those g)
+ * so out[0] / out[1] is the expectation in the post-selected state (fix_mask = 0: plain <O>,
+ * out[1] = norm).  One read pass over the shard(s), 16 B per amplitude.  Multi-process handles
+ * return this rank's partial sums.
+ * Replaces: the opflow expectation of QCMRF.Hamiltonian() / sufficient_statistic()
+ * (QCMRF.py:159-193): H = -sum theta_{C,y} Phi_{C,y} is diagonal in the computational basis. */
+int qsv_expect_diag(qsv_handle* h, const int* qubits, int k, const double* table,
+                    uint64_t fix_mask, uint64_t fix_val, double out[2]);
 
 /* sum |amp|^2 over this process's shards */
 int qsv_norm(qsv_handle* h, double* out);

@@ -113,6 +113,16 @@ class NumpyEngine:
             sv.apply_kq(self.sh[s], list(qubits), u)
 
     def swap_layout(self, a, b):
+        # like libqsv: all shard-bit pairs of ONE call (on distinct qubits) are one exchange step;
+        # pair by pair here, which is the same permutation
+        flat = [q for x, y in zip(a, b) if x != y for q in (x, y)]
+        batched = len(set(flat)) == len(flat)
+        n_before = self.n_exchanges
+        self._swap_pairs(a, b)
+        if batched and self.n_exchanges > n_before:
+            self.n_exchanges = n_before + 1
+
+    def _swap_pairs(self, a, b):
         for x, y in zip(a, b):
             lo, hi = min(x, y), max(x, y)
             if lo == hi:
@@ -212,6 +222,20 @@ class NumpyEngine:
                 j |= ((g >> q) & 1) << b
             out += np.bincount(j[sel], weights=np.abs(self.sh[s][sel]) ** 2, minlength=out.size)
         return out
+
+    def expect_diag(self, qubits, table, fix_mask=0, fix_val=0):
+        table = np.asarray(table, dtype=np.float64)
+        s0 = s1 = 0.0
+        for s in self.owned:
+            g = (s << self.L) | np.arange(2 ** self.L)
+            sel = (g & fix_mask) == fix_val
+            j = np.zeros_like(g)
+            for b, q in enumerate(qubits):
+                j |= ((g >> q) & 1) << b
+            p = np.abs(self.sh[s][sel]) ** 2
+            s0 += float((p * table[j[sel]]).sum())
+            s1 += float(p.sum())
+        return s0, s1
 
     def copy_from(self, other):
         for s in self.owned:

@@ -22,6 +22,12 @@ IPC_HANDLE_BYTES = 64
 K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "exchange", "multi", "multi_init", "init_prod"]
 K_COUNT = len(K_NAMES)
 
+# defaults of the qsv_set_option knobs (qsv.hip: struct qsv_handle), so that a per-run override can be undone
+OPTION_DEFAULTS = {"blocks_per_cu": 1 << 16, "unroll": 4, "lowt_shuffle": 1, "nontemporal": 0, "lane_targets": 1,
+                   "cache_sums": 1, "fused_sums": 1, "pair_variant": 0, "kq_mfma": 1, "zero_tracking": 0, "lane_map": 1,
+                   "init_prod_bit0": 0, "init_prod_r": 0, "init_prod": 1, "pass_hints": 1, "dyn_lanes": 3, "multi_r": 5,
+                   "exchange_chunk_log2": 24}
+
 OP_INIT_ZERO, OP_INIT_UNIFORM, OP_1Q, OP_MCX, OP_DIAG, OP_MCPHASE, OP_MUX, OP_KQ, OP_SWAP = range(9)
 OPF_NEW_PASS = 1
 
@@ -72,6 +78,7 @@ SIGNATURES = {
     "qsv_probabilities": (_i, [_vp, _ip, _i, _dp]),
     "qsv_probabilities_cond": (_i, [_vp, _ip, _i, _u64, _u64, _dp]),
     "qsv_norm": (_i, [_vp, _dp]),
+    "qsv_expect_diag": (_i, [_vp, _ip, _i, _dp, _u64, _u64, _dp]),
     "qsv_sample": (_i, [_vp, _u64, _u64, _ip, _i, _u64p]),
     "qsv_get_amplitudes": (_i, [_vp, _u64, _u64, _dp]),
     "qsv_set_amplitudes": (_i, [_vp, _u64, _u64, _dp]),
@@ -87,6 +94,7 @@ SIGNATURES = {
     "qsv_version": (C.c_char_p, []),
     "qsv_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qsv_rccl_selftest": (C.c_int, [C.c_int, C.c_uint64]),
+    "qsv_rccl_exchange_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "qsv_device_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "qsv_ipc_export": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "qsv_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_char_p, C.c_int]),
@@ -162,6 +170,11 @@ def device_memory(device=0):
 def rccl_selftest(device=0, n_doubles=1 << 20):
     """1-rank RCCL bring-up + grouped send/recv to self on one device (diagnostic)"""
     _chk(load().qsv_rccl_selftest(int(device), int(n_doubles)))
+
+
+def rccl_exchange_selftest(device=0, n_qubits=22, chunk_log2=14):
+    """the RCCL pipeline of a batched exchange (double buffered, several peers) on a 1-rank communicator"""
+    _chk(load().qsv_rccl_exchange_selftest(int(device), int(n_qubits), int(chunk_log2)))
 
 
 def device_bus_id(device=0):
@@ -335,6 +348,17 @@ class Engine:
         _chk(self._lib.qsv_probabilities_cond(self._h, qp, len(qa), int(fix_mask), int(fix_val),
                                               out.ctypes.data_as(_dp)))
         return out
+
+    def expect_diag(self, qubits, table, fix_mask=0, fix_val=0):
+        """(sum |amp|^2 table[j], sum |amp|^2) over the indices g with (g & fix_mask) == fix_val; table is a
+        REAL diagonal over ``qubits`` (index bit b <-> qubits[b]); this process's shards only"""
+        qa, qp = _ia(qubits)
+        ta, tp = _da(table)
+        if ta.size != 1 << len(qa):
+            raise ValueError("diagonal observable has %d entries for %d qubits" % (ta.size, len(qa)))
+        out = np.zeros(2, dtype=np.float64)
+        _chk(self._lib.qsv_expect_diag(self._h, qp, len(qa), tp, int(fix_mask), int(fix_val), out.ctypes.data_as(_dp)))
+        return float(out[0]), float(out[1])
 
     def norm(self):
         v = C.c_double()

@@ -207,7 +207,10 @@ class QsvBackend:
         opts = dict(self.options)
         opts.update(options)
         ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1)
-        ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)))
+        # every qubit of a dense window has to be local to a shard at the same time
+        g = max(1, int(n_shards)).bit_length() - 1
+        ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)),
+                              dense_kmax=max(1, min(5, ing.num_qubits - g)))
         if ing.global_phase and opts.get("apply_global_phase", True):
             from . import ir
             ph = np.exp(1j * ing.global_phase)
@@ -234,6 +237,16 @@ class QsvBackend:
                      "time_sample": 0.0, "seed_simulator": seed, "fusion": opts["fusion"]})
         return {"name": getattr(circuit, "name", "circuit"), "shots": shots, "counts": counts, "metadata": meta}
 
+    @staticmethod
+    def _to_clbits(bits, clist, direct):
+        """sampled words -> classical-register values (bit c = classical bit c)"""
+        if direct:
+            return bits
+        vals = np.zeros(bits.shape, dtype=np.uint64)
+        for j, c in enumerate(clist):
+            vals |= ((bits >> np.uint64(j)) & np.uint64(1)) << np.uint64(c)
+        return vals
+
     def _run_one(self, circuit, shots, seed, opts, prepared=None):
         if opts.get("method", "statevector") == "trajectory":
             return self._run_trajectory(circuit, shots, seed, opts)
@@ -243,8 +256,20 @@ class QsvBackend:
         t0 = t1 - t_compile
 
         eng = self._get_engine(ing.num_qubits, opts)
-        for k, v in (opts["engine_options"] or {}).items():
+        # engine options are per RUN: whatever an earlier call set on the cached engine and this one
+        # does not ask for goes back to the library default first (the plan above was compiled for
+        # exactly this call's options)
+        want = dict(opts["engine_options"] or {})
+        applied = getattr(eng, "_applied_options", None)
+        if applied is None:
+            applied = eng._applied_options = {}
+        for k in [k for k in applied if k not in want]:
+            if k in _lib.OPTION_DEFAULTS:
+                eng.set_option(k, _lib.OPTION_DEFAULTS[k])
+            del applied[k]
+        for k, v in want.items():
             eng.set_option(k, v)
+            applied[k] = v
         if pl.n_exchanges and not eng._comm_ready:
             # collective: RCCL communicator over all ranks, or peer-mapped shards (ranks sharing a GPU)
             eng.comm_bootstrap(comm, device=opts["device"], transport=opts.get("exchange", "auto"))
@@ -269,37 +294,34 @@ class QsvBackend:
             direct = False
         counts = {}
         if clist and shots > 0:
-            if comm.world > 1 and hasattr(comm, "allgather_u64"):
-                # ONE collective per run: every rank draws `shots` outcomes from its own shard (iid
-                # from the shard's conditional law, in shuffled order) and ships them together with
-                # the shard's mass; the common multinomial split then keeps the first split[r] of
-                # rank r's draws.  (Drawing 4096 instead of ~4096/P outcomes costs microseconds; a
-                # second host collective costs more than the whole device part of a sharded run.)
-                mass = eng.norm()
-                mine = eng.sample(shots, (seed * 1315423911 + comm.rank) % (2 ** 63), meas_phys) if mass > 0 \
-                    else np.zeros(shots, dtype=np.uint64)
-                packed = np.empty(shots + 1, dtype=np.uint64)
-                packed[0] = np.array([mass], dtype=np.float64).view(np.uint64)[0]
-                packed[1:] = mine
-                allp = comm.allgather_u64(packed)
-                masses = allp[:, 0].copy().view(np.float64)
+            if comm.world > 1:
+                # Two tiny collectives per run: (1) one double per rank, the shard's probability
+                # mass -> the common multinomial split of the shots over the shards (same seed on
+                # every rank); (2) each rank draws exactly split[rank] outcomes from its own shard
+                # and ships them as (distinct outcome, count) pairs.  Measured against shipping
+                # `shots` draws from every rank in one collective: 8 B + a few hundred pairs per
+                # rank instead of 32 KiB, and each rank samples and sorts 1/P of the shots.
+                masses = np.asarray(comm.allgather_f64(eng.norm()) if hasattr(comm, "allgather_f64")
+                                    else comm.allgather(eng.norm()), dtype=np.float64)
                 split = np.random.RandomState(seed % (2 ** 32)).multinomial(shots, masses / masses.sum())
-                bits = np.concatenate([allp[r, 1:1 + int(split[r])] for r in range(comm.world)])
-            elif comm.world > 1:
-                masses = np.asarray(comm.allgather(eng.norm()), dtype=np.float64)
-                split = np.random.RandomState(seed % (2 ** 32)).multinomial(shots, masses / masses.sum())
-                mine = eng.sample(int(split[comm.rank]), (seed * 1315423911 + comm.rank) % (2 ** 63), meas_phys)
-                bits = np.concatenate(comm.allgather(mine))
+                k = int(split[comm.rank])
+                mine = eng.sample(k, (seed * 1315423911 + comm.rank) % (2 ** 63), meas_phys) if k else np.zeros(0, dtype=np.uint64)
+                uv, uc = np.unique(self._to_clbits(mine, clist, direct), return_counts=True)
+                pairs = np.concatenate([uv, uc.astype(np.uint64)])
+                if hasattr(comm, "allgather_bytes"):
+                    parts = [np.frombuffer(b, dtype=np.uint64) for b in comm.allgather_bytes(pairs.tobytes())]
+                else:
+                    parts = [np.asarray(b, dtype=np.uint64) for b in comm.allgather(pairs)]
+                av = np.concatenate([b[:b.size // 2] for b in parts])
+                ac = np.concatenate([b[b.size // 2:] for b in parts]).astype(np.int64)
+                # shards that differ only in an unmeasured qubit can produce the same outcome
+                uv, inv = np.unique(av, return_inverse=True)
+                uc = np.bincount(inv, weights=ac, minlength=uv.size).astype(np.int64) if uv.size != av.size else ac[np.argsort(av, kind="stable")]
+                counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
             else:
-                bits = eng.sample(shots, seed, meas_phys)
-            if direct:
-                vals = bits
-            else:
-                vals = np.zeros(bits.shape, dtype=np.uint64)
-                for j, c in enumerate(clist):
-                    vals |= ((bits >> np.uint64(j)) & np.uint64(1)) << np.uint64(c)
-            uv, uc = np.unique(vals, return_counts=True)
-            counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
+                vals = self._to_clbits(eng.sample(shots, seed, meas_phys), clist, direct)
+                uv, uc = np.unique(vals, return_counts=True)
+                counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
         elif shots > 0:
             counts = {}
         t3 = time.perf_counter()

@@ -115,6 +115,14 @@ struct Shard {
   // exchange staging (allocated on first use)
   cplx* xbuf[2] = {nullptr, nullptr};
   size_t xbuf_amps = 0;
+  // RCCL exchange pipeline: pack / unpack run on a second stream, overlapping the send/recv of the
+  // neighbouring chunk on the main one; two staging slots per direction, one segment per peer
+  hipStream_t xstream = nullptr;
+  cplx* xsend[2] = {nullptr, nullptr};
+  cplx* xrecv[2] = {nullptr, nullptr};
+  size_t xstage_amps = 0;
+  hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_sent[2] = {nullptr, nullptr}, ev_unpacked[2] = {nullptr, nullptr};
+  hipEvent_t ev_start = nullptr;
   int n_cu = 256;
   uint64_t zmask = 0;            // zero tracking: local bits known |0>; memory with such a bit set is unwritten
   std::vector<double> h_sums;    // host copy of the block sums, valid until the state changes
@@ -338,6 +346,15 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.h_arena) hipHostFree(s.h_arena);
     if (s.d_sums) hipFree(s.d_sums);
     for (int b = 0; b < 2; ++b) if (s.xbuf[b]) hipFree(s.xbuf[b]);
+    for (int b = 0; b < 2; ++b) {
+      if (s.xsend[b]) hipFree(s.xsend[b]);
+      if (s.xrecv[b]) hipFree(s.xrecv[b]);
+      if (s.ev_packed[b]) hipEventDestroy(s.ev_packed[b]);
+      if (s.ev_sent[b]) hipEventDestroy(s.ev_sent[b]);
+      if (s.ev_unpacked[b]) hipEventDestroy(s.ev_unpacked[b]);
+    }
+    if (s.ev_start) hipEventDestroy(s.ev_start);
+    if (s.xstream) { hipStreamSynchronize(s.xstream); hipStreamDestroy(s.xstream); }
     if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
     if (s.d_tsums) hipFree(s.d_tsums);
     if (s.h_tsums) hipHostFree(s.h_tsums);
@@ -465,16 +482,18 @@ extern "C" int qsv_ipc_attach(qsv_handle* h, const uint8_t* handles, const char*
   return QSV_OK;
 }
 
-// both ranks of a pair call this the same number of times; returns once the peer has arrived too
-static int ipc_pair_barrier(qsv_handle* h, int peer) {
+// every rank of a group posts once and waits for all its peers: all ranks run the same program, so
+// their counters advance in lockstep (each exchange = one post before, one after, on every rank)
+static int ipc_group_barrier(qsv_handle* h, const std::vector<int>& peers) {
   const uint64_t seq = ++h->ipc_seq;
   h->ipc_arrive[(size_t)h->rank * QSV_IPC_SLOT].store(seq, std::memory_order_release);
   const auto t0 = std::chrono::steady_clock::now();
-  while (h->ipc_arrive[(size_t)peer * QSV_IPC_SLOT].load(std::memory_order_acquire) < seq) {
-    sched_yield();
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-      return fail(QSV_E_HIP, "rank %d waited 120 s for rank %d at exchange step %llu", h->rank, peer, (unsigned long long)seq);
-  }
+  for (int peer : peers)
+    while (h->ipc_arrive[(size_t)peer * QSV_IPC_SLOT].load(std::memory_order_acquire) < seq) {
+      sched_yield();
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+        return fail(QSV_E_HIP, "rank %d waited 120 s for rank %d at exchange step %llu", h->rank, peer, (unsigned long long)seq);
+    }
   return QSV_OK;
 }
 

@@ -343,6 +343,35 @@ __global__ __launch_bounds__(QSV_TPB) void k_unpack(cplx* __restrict__ amp, cons
   }
 }
 
+// Batched shard-bit <-> local-bit swap (k pairs at once = an all-to-all between the 2^k shards that
+// differ only in those shard bits): shard s keeps the block of its local index space whose k local
+// bits spell its own shard-bit values and trades every other block B with the shard whose shard bits
+// spell B.  `ins` = the k local bit positions (sorted), a block = the 2^(L-k) amplitudes
+// ins_bits(p) | fixed.  In place between two mapped shards:
+__global__ __launch_bounds__(QSV_TPB) void k_swap_blocks(cplx* __restrict__ A, cplx* __restrict__ B, uint64_t p0,
+                                                         uint64_t cnt, BitIns ins, uint64_t fa, uint64_t fb) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
+    const uint64_t i = ins_bits(p0 + q, ins);
+    const cplx x = A[i | fa], y = B[i | fb];
+    A[i | fa] = y;
+    B[i | fb] = x;
+  }
+}
+// ... and through contiguous staging buffers (RCCL): chunk [p0, p0 + cnt) of one block
+__global__ __launch_bounds__(QSV_TPB) void k_pack_block(const cplx* __restrict__ amp, cplx* __restrict__ buf, uint64_t p0,
+                                                        uint64_t cnt, BitIns ins, uint64_t fixed) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride)
+    buf[q] = amp[ins_bits(p0 + q, ins) | fixed];
+}
+__global__ __launch_bounds__(QSV_TPB) void k_unpack_block(cplx* __restrict__ amp, const cplx* __restrict__ buf, uint64_t p0,
+                                                          uint64_t cnt, BitIns ins, uint64_t fixed) {
+  const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
+  for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride)
+    amp[ins_bits(p0 + q, ins) | fixed] = buf[q];
+}
+
 // ---------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------
@@ -404,6 +433,20 @@ __global__ __launch_bounds__(64) void k_locate(const cplx* __restrict__ amp, uin
     }
     if (lane == 0) out[s] = (found == ~0ull) ? last_nz : found;   // rounding slack -> last nonzero
   }
+}
+
+// sampled local indices -> the caller's classical-register layout: bit j <- global index bit pos[j]
+// (pos[j] < 0: a classical bit no measurement writes, stays 0); n < 0: the full global index
+struct MeasMap { int n; signed char pos[64]; };
+__global__ __launch_bounds__(QSV_TPB) void k_remap_bits(uint64_t* __restrict__ idx, uint64_t shots, uint64_t hi, MeasMap mm) {
+  const uint64_t s = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x;
+  if (s >= shots) return;
+  const uint64_t g = idx[s] | hi;
+  if (mm.n < 0) { idx[s] = g; return; }
+  uint64_t bits = 0;
+  for (int j = 0; j < mm.n; ++j)
+    if (mm.pos[j] >= 0) bits |= ((g >> mm.pos[j]) & 1ull) << j;
+  idx[s] = bits;
 }
 
 // Two-level walk over the per-tile sums a program's last pass left behind (2^21 of them for a
@@ -499,6 +542,51 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
     __syncthreads();
     for (int i = threadIdx.x; i < ntab; i += QSV_TPB)
       if (lds_acc[i] != 0.0) atomicAdd(&out[i], lds_acc[i]);
+  }
+}
+
+// expectation of a real DIAGONAL observable over `q` (table[j], j gathered from the global index),
+// restricted to indices with (g & fmask) == fval:  partial[2b] = sum |amp|^2 table[j],
+// partial[2b+1] = sum |amp|^2 over the same indices (the conditioning mass), one pair per workgroup
+// in a fixed order (deterministic).  One read pass: 16 B per amplitude, HBM bound.
+// H = -sum theta Phi of QCMRF.py:181-193 is such an observable on the n variable qubits.
+template <bool LDS>
+__global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict__ amp, uint64_t n, uint64_t hi, BitList q,
+                                                         uint64_t fmask, uint64_t fval, const double* __restrict__ table,
+                                                         int ntab, double* __restrict__ partial) {
+  extern __shared__ double lds_tab[];
+  if (LDS) {
+    for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lds_tab[i] = table[i];
+    __syncthreads();
+  }
+  constexpr int U = 4;
+  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  double s0 = 0.0, s1 = 0.0;
+  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n; base += stride) {
+    cplx a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = base + (uint64_t)u * QSV_TPB;
+      a[u] = i < n ? amp[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t g = hi | (base + (uint64_t)u * QSV_TPB);
+      const double p = ((g & fmask) == fval) ? fma(a[u].x, a[u].x, a[u].y * a[u].y) : 0.0;
+      const uint32_t j = gather_bits(g, q);
+      const double t = LDS ? lds_tab[j] : table[j];
+      s0 = fma(p, t, s0);
+      s1 += p;
+    }
+  }
+  __shared__ double part[2][QSV_TPB / 64];
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    partial[2 * blockIdx.x + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
   }
 }
 

@@ -168,21 +168,25 @@ def _flat(definition):
 
 
 def _and_key(definition):
-    """Structural signature of a small flat definition -- gate names, qubit positions, control
-    state of the middle gate -- or None if it cannot be X..X . MCX . X..X.  Hot: a 34-qubit QCMRF
-    circuit has 304 AND instances (two per clique state, QCMRF.py:225,227) but only 4 distinct
-    signatures; everything beyond reading the signature off the object is memoised on it."""
-    n = len(definition.data)
+    """Structural signature of a small flat definition -- per instruction (name, unconditioned?,
+    qubit positions...), plus the control state of the middle gate -- or None if it cannot be
+    X..X . MCX . X..X.  Hot: a 34-qubit QCMRF circuit has 304 AND instances (two per clique state,
+    QCMRF.py:225,227) but only 4 distinct signatures; everything beyond reading the signature off
+    the object is memoised on it."""
+    data = definition.data
+    n = len(data)
     if not n & 1 or n > 33 or getattr(definition, "global_phase", 0):
         return None
     qs = getattr(definition, "qubits", None)
     if qs is None:
         return None
-    ops, qargs = _flat(definition)
-    if [o for o in ops if getattr(o, "condition", None) is not None]:
-        return None
-    return (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]),
-            tuple([qs.index(q) for qa in qargs for q in qa]), getattr(ops[n >> 1], "ctrl_state", None))
+    ix = qs.index
+    try:
+        sig = tuple([(ci.operation.name, ci.operation.condition is None, *map(ix, ci.qubits)) for ci in data])
+    except AttributeError:                                   # tuple-style instructions / no .condition attribute
+        ops, qargs = _flat(definition)
+        sig = tuple([(o.name, getattr(o, "condition", None) is None, *map(ix, qa)) for o, qa in zip(ops, qargs)])
+    return sig, getattr(_unpack(data[n >> 1])[0], "ctrl_state", None)
 
 
 _SHAPES = {}
@@ -195,15 +199,18 @@ def _shape_of_key(key):
         return _SHAPES[key]
     except KeyError:
         pass
-    names, lens, pos, state = key
-    n = len(names)
+    sig, state = key
+    n = len(sig)
     f = n >> 1
     res = None
-    if names[f] in _MCX_SET and all(nm == "x" and ln == 1 for nm, ln in zip(names[:f] + names[f + 1:], lens[:f] + lens[f + 1:])):
-        head, mid, tail = pos[:f], pos[f:f + lens[f]], pos[f + lens[f]:]
-        ctrls, tgt = list(mid[:-1]), mid[-1]
+    mid = sig[f]
+    sides = sig[:f] + sig[f + 1:]
+    if (mid[0] in _MCX_SET and all(e[1] for e in sig) and len(mid) >= 3
+            and all(e[0] == "x" and len(e) == 3 for e in sides)):
+        head, tail = [e[2] for e in sig[:f]], [e[2] for e in sig[f + 1:]]
+        ctrls, tgt = list(mid[2:-1]), mid[-1]
         vals = [1] * len(ctrls) if state is None else [(int(state) >> i) & 1 for i in range(len(ctrls))]
-        if (sorted(head) == sorted(tail) and len(set(head)) == f and len(set(mid)) == len(mid)
+        if (sorted(head) == sorted(tail) and len(set(head)) == f and len(set(mid[2:])) == len(mid) - 2
                 and tgt not in head and all(x in ctrls for x in head)):
             res = (ctrls, [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)], tgt)
     if len(_SHAPES) > 4096:

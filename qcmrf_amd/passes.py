@@ -29,6 +29,7 @@ from .ir import Op
 
 _X2 = np.array([[0, 1], [1, 0]], dtype=np.complex128)
 SQH = 1.0 / np.sqrt(2.0)
+_SQRT2 = np.sqrt(2.0)
 
 
 def _1q_qubit(op):
@@ -741,17 +742,27 @@ def fold_fresh(ops):
                 sel, tg, mats = mx
                 in_pop = (populated >> tg) & 1
                 if not in_pop or (plus >> tg) & 1:
-                    sq, st = _slice_zero(sel, np.asarray(mats).reshape(-1, 4), populated, ent=4)
-                    st = st.reshape(-1, 2, 2)
-                    if not in_pop and np.array_equal(st, np.broadcast_to(np.eye(2), st.shape)):
+                    smask = 0
+                    for x in sel:
+                        smask |= 1 << x
+                    if smask & ~populated:                  # selects on qubits still |0>: only their 0-slice is read
+                        sq, st = _slice_zero(sel, np.asarray(mats).reshape(-1, 4), populated, ent=4)
+                        st = st.reshape(-1, 2, 2)
+                    else:
+                        sq, st = sel, mats
+                    if not in_pop and not st[:, 1, 0].any() and np.array_equal(st, np.broadcast_to(np.eye(2), st.shape)):
                         continue            # e.g. a control that needs a |0> qubit to be 1: the gate never fires
-                    col = st[:, :, 0] * np.sqrt(2.0) if not in_pop else st[:, :, 0] + st[:, :, 1]
                     # table index: bits 0..k-1 the surviving selects, bit k the target
-                    tab = np.concatenate([col[:, 0], col[:, 1]])
-                    factors.append(ir.op_diag(tuple(sq) + (tg,), tab))
+                    tab = np.empty(2 * st.shape[0], dtype=np.complex128)
+                    half = tab.reshape(2, -1)
+                    if in_pop:
+                        np.add(st[:, :, 0].T, st[:, :, 1].T, out=half)
+                    else:
+                        np.multiply(st[:, :, 0].T, _SQRT2, out=half)
+                    fq = tuple(sq) + (tg,)
+                    factors.append(Op("diag", qubits=fq, table=tab))
                     populated |= 1 << tg
-                    for x in tuple(sq) + (tg,):
-                        plus &= ~(1 << x)
+                    plus &= ~(smask | (1 << tg))
                     done = True
         if not done:
             emitted.append(op)
@@ -776,8 +787,12 @@ def fuse_sandwich(ops):
     other qubits -- one uniformly controlled 2x2.  This is the real-part-extraction block of the
     reference (QCMRF.py:231-236: H, cU, X, cU^dg, X, H) once ingest has emitted cU as a diagonal;
     the monomial and multiplexer windows reach the same op the long way (they stay for
-    everything that does not have exactly this shape)."""
-    out, i, n = [], 0, len(ops)
+    everything that does not have exactly this shape).
+
+    Matching is per op; the arithmetic of all matches with the same table shape runs as ONE batched
+    product (a 34-qubit QCMRF circuit has 19 of them: 19 einsum/snap calls cost more than the rest
+    of the pass pipeline together)."""
+    out, hits, i, n = [], [], 0, len(ops)
     while i < n:
         o = ops[i]
         if i + 5 < n and o.kind == "u" and not o.ctrls:
@@ -787,60 +802,69 @@ def fuse_sandwich(ops):
                     and not x1.ctrls and not x2.ctrls and not u2.ctrls
                     and x1.target == a and x2.target == a and u2.target == a
                     and d1.qubits == d2.qubits and a in d1.qubits and 2 <= len(d1.qubits) <= 9):
-                qs = d1.qubits
-                k = len(qs)
-                ax = k - 1 - qs.index(a)                   # numpy axis of table-index bit e is k-1-e
-                t1 = np.moveaxis(d1.table.reshape((2,) * k), ax, -1).reshape(-1, 2)
-                t2 = np.moveaxis(d2.table.reshape((2,) * k), ax, -1).reshape(-1, 2)
-                e = t2[:, ::-1] * t1
-                mats = np.einsum("ab,sb,bc->sac", u2.mat, e, o.mat)
-                out.append(ir.op_mux([q for q in qs if q != a], a, ir.snap(mats)))
+                hits.append((len(out), o, d1, d2, u2))
+                out.append(None)
                 i += 6
                 continue
         out.append(o)
         i += 1
+    groups = {}
+    for h in hits:
+        qs = h[2].qubits
+        groups.setdefault((len(qs), qs.index(h[1].target)), []).append(h)
+    for (k, e), hs in groups.items():
+        ax = k - e                                             # numpy axis of table-index bit e is k-1-e (+1: batch axis)
+        t1 = np.moveaxis(np.stack([h[2].table for h in hs]).reshape((len(hs),) + (2,) * k), ax, -1).reshape(len(hs), -1, 2)
+        t2 = np.moveaxis(np.stack([h[3].table for h in hs]).reshape((len(hs),) + (2,) * k), ax, -1).reshape(len(hs), -1, 2)
+        ed = t2[:, :, ::-1] * t1                               # (batch, select, target value)
+        u1 = np.stack([h[1].mat for h in hs])                  # (batch, 2, 2)
+        u2 = np.stack([h[4].mat for h in hs])
+        mats = ir.snap(np.matmul(u2[:, None] * ed[:, :, None, :], u1[:, None]))
+        for b, (pos, o, d1, d2, _) in enumerate(hs):
+            a = o.target
+            out[pos] = Op("mux", ctrls=tuple([q for q in d1.qubits if q != a]), target=a, mats=mats[b])
     return out
 
 
 # --------------------------------------------------------------------------------------------
-def _fuse_body(ops, level, kmax, smax, lowered=False):
+def _fuse_body(ops, level, kmax, smax, lowered=False, dense_kmax=5):
     head, body = ops[:1], ops[1:]
     if lowered and level >= 3:
         # basis-gate input: re-assemble the blocks first, while the gate order is still pristine
-        body = fuse_dense(body)
+        body = fuse_dense(body, kmax=dense_kmax)
     if level >= 2:
         body = fuse_sandwich(body)
     body = fuse_monomial(body, kmax=kmax)
     if level >= 2:
         body = fuse_mux(body, smax=smax)
     if level >= 3 and not lowered:
-        body = fuse_dense(body)
+        body = fuse_dense(body, kmax=dense_kmax)
     return head + body
 
 
-def optimise(ops, level=3, kmax=10, smax=8, fresh=True):
+def optimise(ops, level=3, kmax=10, smax=8, fresh=True, dense_kmax=5):
     """level 0: gate by gate as ingested (|0..0> init prepended).
     level 1: + init folding + diagonal (monomial) fusion.   level 2: + multiplexer fusion.
     level 3: + dense <= 5-qubit windows with structure recovery (for basis-gate circuits)
              + (``fresh``) gates on untouched qubits folded into the initial product state."""
-    out = _optimise(ops, level, kmax, smax)
+    out = _optimise(ops, level, kmax, smax, dense_kmax)
     return fold_fresh(out) if (fresh and level >= 3) else out
 
 
-def _optimise(ops, level, kmax, smax):
+def _optimise(ops, level, kmax, smax, dense_kmax=5):
     if level <= 0:
         return [ir.op_init(0)] + list(ops)
     lead, rest = split_leading(ops)
     cands = set(q for q, m in lead.items() if _is_hlike(m))
     hold0 = set(q for op in rest for q in op.dense_targets()) & cands
     if level < 3 or hold0 != cands or not cands:
-        return _fuse_body(fold_init(ops, hold=hold0), level, kmax, smax)
+        return _fuse_body(fold_init(ops, hold=hold0), level, kmax, smax, dense_kmax=dense_kmax)
     # every candidate looks dense in the raw stream: a circuit lowered to basis gates, where even
     # pure select qubits are CX targets inside decompositions (and a CCX opens with rz-sx-rz on
     # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the
     # variable qubits' opening gates stand alone in front and are never dense again, so the
     # ordinary rule applies to it.
-    fused = _fuse_body(fold_init(ops, hold=cands), level, kmax, smax, lowered=True)
+    fused = _fuse_body(fold_init(ops, hold=cands), level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
     refolded = fold_init(fused[1:])
     refolded[0].mask |= fused[0].mask
     return refolded

@@ -180,8 +180,9 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
     return lay
 
 
-def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True, dyn_lanes=DYN_LANES):
-    """ops on logical qubits (first op is ``init``) -> Plan with physical ops."""
+def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True, dyn_lanes=DYN_LANES, batch_swaps=True):
+    """ops on logical qubits (first op is ``init``) -> Plan with physical ops.
+    ``n_exchanges`` counts exchange STEPS: a batched swap of several shard bits is one."""
     if n_shards < 1 or n_shards & (n_shards - 1):
         raise ValueError("number of shards must be a power of two")
     g = n_shards.bit_length() - 1
@@ -208,18 +209,34 @@ def plan(ops, n_qubits, n_shards=1, layout="auto", lane_targets=True, dyn_lanes=
 
     for k, op in enumerate(ops):
         if g:
-            for t in op.dense_targets():
-                if lay[t] < L:
-                    continue
-                busy = set(op.support())
+            need = [t for t in op.dense_targets() if lay[t] >= L]
+            if need:
+                # Only the op's dense targets have to be local: its controls / selects may well be the
+                # ones evicted to a shard bit (libqsv resolves those per shard).  Victims by Belady's
+                # rule: the local qubit whose next dense use is farthest away (never, if possible).
+                busy = set(op.dense_targets())
                 inv = {p: q for q, p in enumerate(lay)}
-                cands = [inv[p] for p in range(L) if inv[p] not in busy]
-                if not cands:
-                    raise ValueError("gate %r leaves no local qubit free for an exchange" % (op,))
-                victim = max(cands, key=lambda q: (next_dense(q, k), lay[q]))
-                P.ops.append(ir.Op("swap", a=(lay[t],), b=(lay[victim],)))
+                victims = sorted((inv[p] for p in range(L) if inv[p] not in busy),
+                                 key=lambda q: (next_dense(q, k), lay[q]), reverse=True)
+                # ONE batched exchange: every other qubit sitting on a shard bit that will be a dense
+                # target later rides along now (an all-to-all moves (2^k - 1) / 2^k of a shard over
+                # 2^k - 1 links at once; k separate exchanges move k / 2 of it over one link each),
+                # as long as the local qubit that makes room is needed later than it
+                riders = sorted((q for q in range(n_qubits) if lay[q] >= L and q not in need
+                                 and next_dense(q, k) <= len(ops)), key=lambda q: next_dense(q, k)) if batch_swaps else []
+                pairs = []
+                for t in need + riders:
+                    if not victims:
+                        if t in need:
+                            raise ValueError("gate %r leaves no local qubit free for an exchange" % (op,))
+                        break
+                    if t not in need and next_dense(victims[0], k) <= next_dense(t, k):
+                        break
+                    pairs.append((t, victims.pop(0)))
+                P.ops.append(ir.Op("swap", a=tuple(lay[t] for t, _ in pairs), b=tuple(lay[v] for _, v in pairs)))
                 P.n_exchanges += 1
-                lay[t], lay[victim] = lay[victim], lay[t]
+                for t, v in pairs:
+                    lay[t], lay[v] = lay[v], lay[t]
         P.ops.append(_remap(op, lay))
         # pass boundary chosen with the layout: the first gate on the first target of a later pass
         hit = heads.intersection(op.dense_targets())

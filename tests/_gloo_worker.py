@@ -1,7 +1,12 @@
-"""Worker of tests/test_multiproc_gloo.py: one rank per shard over gloo (CPU).  The engine is the
-numpy stand-in (this container has no GPU); everything above it -- planner, program encoding,
-the backend's multi-process run(), exchange orchestration, mass all-gather, multinomial shot
-split, outcome merge -- is the shipped code."""
+"""Worker of tests/test_multiproc_gloo.py: one rank per shard (CPU).  The engine is the numpy
+stand-in (this container has no GPU); everything above it -- planner, program encoding, the
+backend's multi-process run(), exchange orchestration, mass all-gather, multinomial shot split,
+outcome merge -- is the shipped code.
+
+argv[2] = transport of the host collectives and of the stand-in engine's shard exchange:
+  gloo    torch.distributed (tests/_torch_comm.py), launched by torch.distributed.run
+  socket  qcmrf_amd.comm.SocketComm -- the package's own stdlib process group -- launched as plain
+          processes with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment"""
 import json
 import os
 import sys
@@ -12,31 +17,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import torch                                         # noqa: E402
-import torch.distributed as dist                     # noqa: E402
-
 from oracle import closed_form as cf                 # noqa: E402
 from oracle.sharded_numpy import NumpyEngine         # noqa: E402
 from qcmrf_amd import QCMRF, workloads               # noqa: E402
 from qcmrf_amd.backend import QsvBackend             # noqa: E402
-from qcmrf_amd.comm import TorchDistComm             # noqa: E402
 
 
 def main():
     out_path = sys.argv[1]
-    comm = TorchDistComm("gloo")
-    rank, world = comm.rank, comm.world
+    transport = sys.argv[2] if len(sys.argv) > 2 else "gloo"
+    if transport == "gloo":
+        import torch
+        import torch.distributed as dist
+        from _torch_comm import TorchDistComm
+        comm = TorchDistComm("gloo")
 
-    def exchange(me, peer, send):
-        t_send = torch.from_numpy(np.ascontiguousarray(send).view(np.float64).copy())
-        t_recv = torch.empty_like(t_send)
-        if me < peer:
-            dist.send(t_send, dst=peer)
-            dist.recv(t_recv, src=peer)
-        else:
-            dist.recv(t_recv, src=peer)
-            dist.send(t_send, dst=peer)
-        return t_recv.numpy().view(np.complex128)
+        def exchange(me, peer, send):
+            t_send = torch.from_numpy(np.ascontiguousarray(send).view(np.float64).copy())
+            t_recv = torch.empty_like(t_send)
+            if me < peer:
+                dist.send(t_send, dst=peer)
+                dist.recv(t_recv, src=peer)
+            else:
+                dist.recv(t_recv, src=peer)
+                dist.send(t_send, dst=peer)
+            return t_recv.numpy().view(np.complex128)
+    else:
+        from qcmrf_amd.comm import SocketComm
+        assert "torch" not in sys.modules
+        comm = SocketComm(timeout_s=120)
+
+        def exchange(me, peer, send):                 # every rank exchanges at the same program point
+            return comm.allgather(np.ascontiguousarray(send))[peer]
+    rank, world = comm.rank, comm.world
 
     def factory(n_qubits, devices=(0,), rank=None, world_size=None):
         assert rank == comm.rank and world_size == comm.world
@@ -77,7 +90,11 @@ def main():
     if rank == 0:
         json.dump(results, open(out_path, "w"))
     comm.barrier()
-    dist.destroy_process_group()
+    if transport == "gloo":
+        dist.destroy_process_group()
+    else:
+        assert "torch" not in sys.modules            # the package's own process group never needs it
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_multiproc.py: one libqsv rank per PROCESS, both on device 0 (the test
-box has one GPU), host-side rendezvous over gloo.  RCCL refuses two ranks on one device, so the
+box has one GPU), host-side rendezvous over the package's own process group (qcmrf_amd.comm).  RCCL refuses two ranks on one device, so the
 shard-bit exchange goes over the peer-mapped (HIP IPC) transport; everything else -- planner swap
 insertion, qsv_create_rank, per-shard gate resolution, the one-collective sampling merge -- is
 the path a real multi-GPU launch takes."""
@@ -20,7 +20,7 @@ assert _lib.device_count() >= 1
 from oracle import closed_form as cf                 # noqa: E402
 from qcmrf_amd import QCMRF, workloads               # noqa: E402
 from qcmrf_amd.backend import QsvBackend             # noqa: E402
-from qcmrf_amd.comm import TorchDistComm             # noqa: E402
+from qcmrf_amd.comm import SocketComm                # noqa: E402
 
 
 def config4(comm, out_path):
@@ -74,12 +74,11 @@ def config4(comm, out_path):
 
 def main():
     out_path = sys.argv[1]
-    comm = TorchDistComm("gloo")
+    comm = SocketComm(timeout_s=300)
     rank, world = comm.rank, comm.world
     if len(sys.argv) > 2 and sys.argv[2] == "config4":
         config4(comm, out_path)
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        comm.close()
         return
     C = workloads.chain(8)                            # n = 8, m = 7, W = 16: L = 15 / 14 local qubits
     th = workloads.theta_halfnorm(workloads.dimension(C))
@@ -120,8 +119,8 @@ def main():
     if rank == 0:
         json.dump(results, open(out_path, "w"))
     comm.barrier()
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    assert "torch" not in sys.modules                # launched by torch.distributed.run, never imported here
+    comm.close()
 
 
 if __name__ == "__main__":

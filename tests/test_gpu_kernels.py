@@ -172,6 +172,59 @@ def test_swap_layout_local(lib):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_swap_layout_batched_shard_bits_is_one_all_to_all(lib, P):
+    """several (shard bit, local bit) pairs in ONE qsv_swap_layout call = one batched exchange (an
+    all-to-all inside each group of shards): same permutation as the pairs one after the other
+    (numpy engine), counted as ONE exchange; subsets of the shard bits; mixed with a local swap"""
+    from oracle.sharded_numpy import NumpyEngine
+    W = 15
+    g = P.bit_length() - 1
+    L = W - g
+    rs = np.random.RandomState(40 + P)
+    cases = []
+    shard_bits = list(range(L, W))
+    for k in range(1, g + 1):
+        for trial in range(3):
+            G = [int(x) for x in rs.choice(shard_bits, size=k, replace=False)]
+            J = [int(x) for x in rs.choice(L, size=k, replace=False)]
+            cases.append((G, J))
+    with lib.Engine(W, devices=(0,) * P) as e:
+        for G, J in cases:
+            ref = NumpyEngine(W, P)
+            st = rand_state(W, len(G) * 7 + J[0])
+            for s in range(P):
+                ref.sh[s][:] = st[s << L:(s + 1) << L]
+            e.set_amplitudes(0, st)
+            e.reset_stats()
+            # caller's pair order is arbitrary: (a, b) with the shard bit on either side
+            a = [G[i] if i % 2 == 0 else J[i] for i in range(len(G))]
+            b = [J[i] if i % 2 == 0 else G[i] for i in range(len(G))]
+            e.swap_layout(a, b)
+            ref.swap_layout(a, b)
+            assert np.array_equal(e.amplitudes(), ref.amplitudes()), (G, J)
+            assert e.stats()["exchanges"] == 1, (G, J)
+        # a local pair in the same call, and a call whose pairs share a qubit (executed one by one)
+        st = rand_state(W, 99)
+        ref = NumpyEngine(W, P)
+        for s in range(P):
+            ref.sh[s][:] = st[s << L:(s + 1) << L]
+        e.set_amplitudes(0, st)
+        a, b = [W - 1, 2, 5], [4, 9, W - 1] if g >= 1 else [4, 9, 6]
+        e.swap_layout(a, b)
+        ref.swap_layout(a, b)
+        assert np.array_equal(e.amplitudes(), ref.amplitudes())
+
+
+def test_rccl_exchange_pipeline_selftest(lib):
+    """the RCCL side of a batched exchange -- staging, two-stream double buffering, grouped send/recv
+    to two 'peers' -- on a 1-rank communicator (RCCL refuses two ranks on one device): many small
+    chunks (pipeline depth), one chunk, and a chunk size that does not divide the block"""
+    lib.rccl_exchange_selftest(0, 22, 12)       # 2^20-amplitude blocks in 256 chunks
+    lib.rccl_exchange_selftest(0, 18, 30)       # everything in one chunk
+    lib.rccl_exchange_selftest(0, 20, 17)
+
+
 def test_direct_shard_bit_swap_after_exec_drops_the_cached_tile_sums(lib):
     """qsv_exec leaves per-tile |amp|^2 sums for sampling; a qsv_swap_layout across a shard bit
     issued directly through the C ABI afterwards (Engine.swap_layout) moves amplitudes between

@@ -41,6 +41,8 @@ def test_ranks_as_processes_on_one_gpu(tmp_path, world):
     assert res["auto/3"]["n_exchanges"] == 0 and res["auto/2"]["n_exchanges"] == 0     # exchange-free layouts
     assert res["reference/2"]["n_exchanges"] >= 1 and res["reference/0"]["n_exchanges"] >= 1
     assert res["reference/2"]["transport"] == "p2p"          # two ranks on one device: RCCL is not an option
+    # fused circuit, ancillas on the shard bits: ALL shard bits are swapped in by one batched exchange
+    assert res["reference/2"]["n_exchanges"] == 1
 
 
 @pytest.mark.parametrize("world", [2, 4])

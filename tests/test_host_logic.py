@@ -409,3 +409,68 @@ def test_fold_fresh_rules():
     assert [o.kind for o in passes.fold_fresh(blocked)] == ["init", "kq", "u"]
     # a program that does not start with init is left alone
     assert passes.fold_fresh(base[1:]) == base[1:]
+
+
+def test_dense_windows_never_outgrow_the_local_qubits():
+    """fusion 3 builds dense windows of up to 5 qubits; on 4 shards of a 6-qubit circuit only 4
+    qubits are local, and a window as wide as that would leave the planner no local qubit to swap a
+    shard-bit target in with (it used to raise 'leaves no local qubit free').  backend.compile caps
+    the window width at L, and the planner may evict a gate's own controls / selects to shard bits."""
+    for seed in range(12):
+        for nq in (5, 6):
+            qc = rand_circuit(nq, 60, 900 + seed)
+            want = oracle_state_of(qc)
+            for shards in (2, 4):
+                for layout in ("auto", "reference"):
+                    amp, ing, pl, eng = run_numpy(qc, fusion=3, shards=shards, layout=layout)
+                    assert np.abs(amp - want).max() < 1e-12, (seed, nq, shards, layout)
+                    L = nq - (shards.bit_length() - 1)
+                    assert all(len(o.qubits) <= L for o in pl.ops if o.kind == "kq")
+
+
+def test_engine_options_are_per_run():
+    """run(..., engine_options={...}) must not leak into later runs on the cached engine"""
+    calls = []
+
+    class Eng(NumpyEngine):
+        def set_option(self, name, value):
+            calls.append((name, value))
+
+    be = QsvBackend()
+    be._engine_factory = lambda n, devices=(0,), rank=None, world_size=None: Eng(n, len(devices))
+    qc = QCMRF([[0, 1], [1, 2]], random_theta(8))
+    be.run(qc, shots=10, seed_simulator=1, engine_options={"zero_tracking": 1, "multi_r": 3})
+    assert calls == [("zero_tracking", 1), ("multi_r", 3)]
+    del calls[:]
+    be.run(qc, shots=10, seed_simulator=1, engine_options={"multi_r": 2})
+    assert calls == [("zero_tracking", 0), ("multi_r", 2)]           # the override of the first run is undone
+    del calls[:]
+    be.run(qc, shots=10, seed_simulator=1)
+    assert calls == [("multi_r", 5)]
+    del calls[:]
+    be.run(qc, shots=10, seed_simulator=1)
+    assert calls == []
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_planner_batches_shard_bit_swaps_into_one_exchange(P):
+    """reference layout of a fused QCMRF circuit: the last log2(P) ancillas -- dense targets -- sit on
+    the shard bits (QCMRF.py:231, qubit n+1+ii).  The planner brings them ALL in with one batched
+    swap when the first of them is needed (one all-to-all), not one half-shard exchange each."""
+    C = workloads.grid(2, 3)                          # n = 6, m = 7, W = 14
+    th = random_theta(cf.model_shape(C)[3], seed=P)
+    qc = QCMRF(C, th)
+    g = P.bit_length() - 1
+    amp, ing, pl, eng = run_numpy(qc, fusion=2, shards=P, layout="reference")
+    assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-13
+    swaps = [o for o in pl.ops if o.kind == "swap"]
+    assert len(swaps) == 1 and len(swaps[0].a) == g and pl.n_exchanges == 1 == eng.n_exchanges
+    L = 14 - g
+    assert all(x >= L for x in swaps[0].a) and all(x < L for x in swaps[0].b)
+    # one at a time (batch_swaps off) is the same state with g exchange steps
+    ops = passes.optimise(ing.ops, level=2)
+    pl1 = planner.plan(ops, 14, P, "reference", batch_swaps=False)
+    assert pl1.n_exchanges == g and all(len(o.a) == 1 for o in pl1.ops if o.kind == "swap")
+    e1 = NumpyEngine(14, P)
+    program.run_stepwise(e1, pl1.ops)
+    assert np.abs(logical_amplitudes(e1, pl1.layout, 14) - cf.amplitudes(C, th)).max() < 1e-13

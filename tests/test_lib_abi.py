@@ -65,3 +65,6 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "qsv_ref" not in txt, f
+                # host side = Python + numpy + ctypes (north star): no PyTorch anywhere in the package,
+                # not even for the multi-process rendezvous (qcmrf_amd.comm is standard library only)
+                assert not re.search(r"^\s*(from|import)\s+torch\b", txt, flags=re.M), f
