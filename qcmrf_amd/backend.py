@@ -119,6 +119,7 @@ class QsvBackend:
         self._engine_key = None
         self.last_engine = None
         self.last_plan = None
+        self._last_comm = None
         self._engine_factory = None      # test hook only; the default and only shipped engine is libqsv
 
     def name(self):
@@ -161,6 +162,28 @@ class QsvBackend:
         out = np.empty_like(amp)
         out[l] = amp
         return out
+
+    def expectation_diagonal(self, diag, qubits, fixed=None):
+        """(sum |amp|^2 diag[j], sum |amp|^2) over the basis states in which every qubit of ``fixed``
+        ({logical qubit: 0/1}) has the given value, on the state the LAST run left in HBM; ``diag`` is
+        a real diagonal over the logical ``qubits`` (index bit b <-> qubits[b]).  The first divided by
+        the second is the expectation in the post-selected state.  One read pass on the device
+        (qsv_expect_diag); summed over the ranks of a multi-process run.  Replaces the opflow
+        expectation of QCMRF.Hamiltonian() / sufficient_statistic() (QCMRF.py:159-193)."""
+        eng, pl = self.last_engine, self.last_plan
+        if eng is None or pl is None:
+            raise RuntimeError("expectation_diagonal needs a state: run() a circuit on this backend first")
+        phys = [pl.layout[q] for q in qubits]
+        fm = fv = 0
+        for q, v in (fixed or {}).items():
+            fm |= 1 << pl.layout[q]
+            fv |= int(bool(v)) << pl.layout[q]
+        s0, s1 = eng.expect_diag(phys, np.ascontiguousarray(diag, dtype=np.float64), fm, fv)
+        comm = self._last_comm
+        if comm is not None and comm.world > 1:
+            parts = comm.allgather((s0, s1))
+            s0, s1 = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        return s0, s1
 
     def close(self):
         if self._engine is not None:
@@ -334,6 +357,7 @@ class QsvBackend:
             eng.set_profiling(False)
         self.last_engine = eng
         self.last_plan = pl
+        self._last_comm = comm
         return {"name": getattr(circuit, "name", "circuit"), "shots": shots, "counts": counts, "metadata": meta}
 
 

@@ -89,6 +89,13 @@ static int rccl_load() {
   g_rccl.lib = lib;
   return QSV_OK;
 }
+// RCCL announces itself on stdout when a communicator comes up ("RCCL version : ..."); stdout
+// belongs to the caller (bench.py prints exactly one JSON line there): keep the banner on stderr
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+  ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); dup2(saved, 1); close(saved); } }
+};
 #define NCCLCHK(expr)                                                                     \
   do {                                                                                    \
     ncclResult_t r_ = (expr);                                                             \
@@ -140,6 +147,7 @@ struct Shard {
   LanePos tile_lp;
   BitIns tile_ins;
   uint64_t tile_nblocks = 0;
+  uint64_t tile_xor = 0;         // X frame of that pass: tile addresses are XOR-ed with it
   uint64_t* d_sblk = nullptr;    // sampling scratch (block index, residual, result per shot)
   double* d_sres = nullptr;
   uint64_t* d_sout = nullptr;
@@ -181,6 +189,8 @@ struct qsv_handle {
   int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
+  int opt_xframe = 1;                 // uncontrolled X gates inside a pass become an XOR on its store addresses
+  int opt_pass_budget = 0;            // opt-in cap on the arithmetic of a general pass, percent of one read+write of the shard (0: none)
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
 };
 
@@ -435,6 +445,7 @@ extern "C" int qsv_comm_init(qsv_handle* h, const uint8_t id[QSV_UNIQUE_ID_BYTES
   CHK(shard_set(h->shards[0]));
   ncclUniqueId uid;
   memcpy(&uid, id, QSV_UNIQUE_ID_BYTES);
+  StdoutToStderr quiet;
   NCCLCHK(g_rccl.CommInitRank(&h->comm, h->P, uid, h->rank));
   return QSV_OK;
 }
@@ -507,6 +518,7 @@ extern "C" int qsv_rccl_selftest(int device_id, uint64_t n_doubles) {
   ncclUniqueId uid;
   NCCLCHK(g_rccl.GetUniqueId(&uid));
   ncclComm_t comm = nullptr;
+  StdoutToStderr quiet;
   NCCLCHK(g_rccl.CommInitRank(&comm, 1, uid, 0));
   hipStream_t st = nullptr;
   double *a = nullptr, *b = nullptr;

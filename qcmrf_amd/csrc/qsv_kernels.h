@@ -695,10 +695,14 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-      const bool fire = (((unsigned)j0 & op.rmask) == op.rval) && ct;
-      const cplx x = a[j0], y = a[j1];
-      a[j0] = make_double2(fire ? y.x : x.x, fire ? y.y : x.y);
-      a[j1] = make_double2(fire ? x.x : y.x, fire ? x.y : y.y);
+      // the register part of the condition is wave-uniform (j0 is a compile-time constant): a scalar
+      // branch skips the pairs it rules out -- CCX with both controls on register bits touches a
+      // quarter of the tile -- and only the lane / block part costs selects
+      if (((unsigned)j0 & op.rmask) == op.rval) {
+        const cplx x = a[j0], y = a[j1];
+        a[j0] = make_double2(ct ? y.x : x.x, ct ? y.y : x.y);
+        a[j1] = make_double2(ct ? x.x : y.x, ct ? x.y : y.y);
+      }
     }
   } else {   // type 2: one matrix where the controls match
     const bool ct = (base & op.tmask) == op.tval;
@@ -835,10 +839,12 @@ __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op,
     }
   } else {   // type 3
     const bool ct = (base & op.tmask) == op.tval;
-    const cplx ph = make_double2(op.m[0], op.m[1]);
+    // multiply by the phase where the lane / block controls match, by 1 elsewhere: no divergent
+    // branch; the register controls are a scalar (wave-uniform) test per amplitude
+    const cplx ph = make_double2(ct ? op.m[0] : 1.0, ct ? op.m[1] : 0.0);
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j)
-      if ((((unsigned)j & op.rmask) == op.rval) && ct) a[j] = cmul(a[j], ph);
+      if (((unsigned)j & op.rmask) == op.rval) a[j] = cmul(a[j], ph);
   }
 }
 
@@ -875,7 +881,10 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
                                                    const MultiSlot* __restrict__ slots, int nrounds,
                                                    const cplx* __restrict__ tables, int ntab,
                                                    uint64_t nonmask, double initval,
-                                                   unsigned int zreg, double* __restrict__ tile_sums) {
+                                                   unsigned int zreg, double* __restrict__ tile_sums, uint64_t xmask) {
+  // xmask (X frame): uncontrolled X gates of the pass are not executed as data movement at all --
+  // the host conjugates every later op of the pass by them and the pass STORES each amplitude at
+  // (its address XOR xmask): a wave store stays one contiguous run, the permutation is free.
   // zreg (zero tracking): register bits whose qubit is still known to be |0> on entry -- every
   // amplitude with such a bit set is zero by construction and is not read (memory there may be
   // unwritten).  `ins` then also holds the known-zero NON-register bits, so only the populated
@@ -966,13 +975,21 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     if constexpr (R > 4) multi_slot<R, 4, MODE>(a, ops, rs, base, lt);
     if constexpr (R > 5) multi_slot<R, 5, MODE>(a, ops, rs, base, lt);
   }
+  // store side of the X frame: register, lane and block part of the mask
+  uint64_t regbits = 0;
+#pragma unroll
+  for (int c = 0; c < R; ++c) regbits |= ob[c];
+  const uint64_t xreg = xmask & regbits, xrest = xmask & ~regbits;
+  const uint32_t thrbits = tile_base_thr(QSV_TPB - 1, ins, lp);
+  cplx* __restrict__ pst = amp + (base_blk ^ (xrest & ~(uint64_t)thrbits));
+  const uint32_t thr_st = base_thr ^ (uint32_t)(xrest & thrbits);
   double psum = 0.0;
 #pragma unroll
   for (int j = 0; j < (1 << R); ++j) {
     uint64_t off = 0;
 #pragma unroll
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-    (pblk + off)[base_thr] = a[j];
+    (pst + (off ^ xreg))[thr_st] = a[j];
     psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
   }
   // last pass of a program: leave sum |amp|^2 of this workgroup's tile behind, so that measurement
@@ -1198,13 +1215,14 @@ template <int R>
 __global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict__ amp, BitIns ins, RegPos rp, LanePos lp,
                                                          const uint64_t* __restrict__ blk,
                                                          const double* __restrict__ resid,
-                                                         uint64_t* __restrict__ out, uint64_t shots) {
+                                                         uint64_t* __restrict__ out, uint64_t shots, uint64_t xmask) {
   __shared__ double wtot[QSV_TPB / 64];
   __shared__ unsigned long long found;
   __shared__ unsigned long long lastnz;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint64_t s = blockIdx.x; s < shots; s += gridDim.x) {
-    const uint64_t base = tile_base_blk(blk[s], ins, lp) | tile_base_thr(threadIdx.x, ins, lp);
+    // the pass stored every amplitude of the tile at (tile address XOR xmask): the X frame
+    const uint64_t base = (tile_base_blk(blk[s], ins, lp) | tile_base_thr(threadIdx.x, ins, lp)) ^ xmask;
     const double r = resid[s];
     double p[1 << R];
     double mine = 0.0;
@@ -1213,7 +1231,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict_
       uint64_t off = 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= 1ull << rp.pos[c];
-      const cplx a = amp[base | off];
+      const cplx a = amp[base ^ off];                     // (tile address | off) ^ xmask
       p[j] = fma(a.x, a.x, a.y * a.y);
       mine += p[j];
     }
@@ -1242,7 +1260,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict_
       uint64_t off = 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((jhit >> c) & 1) off |= 1ull << rp.pos[c];
-      atomicMin(&found, (unsigned long long)(base | off));
+      atomicMin(&found, (unsigned long long)(base ^ off));
     }
     __syncthreads();
     if (found == ~0ull && lastnz != ~0ull && threadIdx.x == (unsigned)lastnz) {
@@ -1253,7 +1271,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_locate_tile(const cplx* __restrict_
       uint64_t off = 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((jlast >> c) & 1) off |= 1ull << rp.pos[c];
-      found = base | off;
+      found = base ^ off;
     }
     __syncthreads();
     if (threadIdx.x == 0) out[s] = found;

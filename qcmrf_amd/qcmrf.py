@@ -6,9 +6,10 @@ that ``run_experiment.py`` style scripts run unchanged.  When Qiskit is importab
 derives from the real ``qiskit.QuantumCircuit`` (and uses the real ``AND``); otherwise from the
 container in ``qcmrf_amd.circuit``.  Either way the object is what the engine's ingest reads.
 
-Out of scope: ``sufficient_statistic`` / ``Hamiltonian`` in their opflow form
-(QCMRF.py:159-197) -- opflow was removed from Qiskit and nothing on the simulation path uses
-them; ``hamiltonian_diagonal`` gives the same operator as the diagonal it is.
+``sufficient_statistic`` / ``Hamiltonian`` (QCMRF.py:159-197) exist here as the diagonals they are
+(``hamiltonian_diagonal``, ``sufficient_statistic_diagonal``: opflow was removed from Qiskit), with
+their expectation values evaluated on the device (``expectation_hamiltonian``,
+``expectation_sufficient_statistic`` -> libqsv ``qsv_expect_diag``).
 """
 from __future__ import annotations
 
@@ -120,6 +121,31 @@ class QCMRF(QuantumCircuit):
         for v, b in zip(C, y):
             d *= (((idx >> (n - 1 - v)) & 1) == int(bool(b)))
         return d
+
+    def expectation_hamiltonian(self, backend, post_selected=True, **run_options):
+        """<H> of ``Hamiltonian()`` (QCMRF.py:181-193) in the state this circuit prepares, evaluated on
+        the device: the circuit is run on ``backend`` (no shots) and the diagonal H is averaged over
+        the resident amplitudes in one read pass.  post_selected=True: in the state conditioned on
+        every ancilla (and the AND scratch qubit) reading 0 -- the Gibbs state the construction
+        targets.  Returns (<H>, probability of that condition)."""
+        backend.run(self, shots=0, **run_options)
+        n, W = self._n, self._n + self._num_cliques + 1
+        fixed = {q: 0 for q in range(n, W)} if post_selected else None
+        s0, s1 = backend.expectation_diagonal(self.hamiltonian_diagonal(), list(range(n)), fixed)
+        return s0 / s1, s1
+
+    def expectation_sufficient_statistic(self, backend, C, y, post_selected=True, **run_options):
+        """<Phi_{C,y}> of ``sufficient_statistic(C, y)`` (QCMRF.py:159-179): the probability that the
+        variables of C read y, same conventions as ``expectation_hamiltonian``"""
+        backend.run(self, shots=0, **run_options)
+        n, W = self._n, self._n + self._num_cliques + 1
+        fixed = {q: 0 for q in range(n, W)} if post_selected else None
+        # Phi only looks at the clique's own qubits: variable v lives on qubit n-1-v (QCMRF.py:219)
+        qs = [n - 1 - v for v in C]
+        tab = np.zeros(2 ** len(qs))
+        tab[sum(int(bool(b)) << e for e, b in enumerate(y))] = 1.0
+        s0, s1 = backend.expectation_diagonal(tab, qs, fixed)
+        return s0 / s1, s1
 
     # ---- circuit construction (QCMRF.py:199-243) ---------------------------------------------
     def _clique_unitary(self, index, C, first_param):

@@ -639,3 +639,34 @@ def test_larger_cliques_all_paths(be, cliques):
     be.run(QCMRF(cliques, th), shots=0)
     kinds = be.last_engine.stats()["kinds"]
     assert set(kinds) == {"init_prod"}, kinds
+
+
+def test_expectation_hamiltonian_on_device(be):
+    """f4 (QCMRF.py:159-193): <H> and <Phi_{C,y}> evaluated by qsv_expect_diag on the resident state.
+    W = 20: against the Gibbs average from the closed-form oracle (H = -log p - log Z, not the
+    product's own diagonal), every execution path, 1 and 4 shards; W = 28 (4 GiB): the same
+    through the size-independent identity <H>_post = sum_x p(x) H(x) with p, Z from the exact MRF sum."""
+    from qcmrf_amd import QCMRF, workloads
+    C = gs.chain_cliques(10)                                   # n = 10, m = 9, W = 20
+    th = random_theta(36, seed=4)
+    qc = QCMRF(C, th)
+    p, Z = cf.gibbs_pmf(C, th)
+    H = -(np.log(p) + np.log(Z))
+    for opts in ({}, {"fold_fresh": False}, {"fusion": 0}, {"devices": (0,) * 4}, {"devices": (0,) * 4, "layout": "reference", "fold_fresh": False}):
+        val, prob = qc.expectation_hamiltonian(be, **opts)
+        assert abs(val - float((p * H).sum())) < 1e-11 and abs(prob - Z / 2 ** 10) < 1e-12, opts
+        val, prob = qc.expectation_hamiltonian(be, post_selected=False, **opts)
+        assert abs(val - H.mean()) < 1e-11 and abs(prob - 1.0) < 1e-12, opts
+    for Cq, y in ((C[0], (0, 1)), (C[5], (1, 1))):
+        val, _ = qc.expectation_sufficient_statistic(be, Cq, y, devices=(0,))
+        assert abs(val - float((p * qc.sufficient_statistic_diagonal(Cq, y)).sum())) < 1e-12
+    name, C = workloads.baseline_config(2)                     # W = 28
+    th = random_theta(60, seed=5)
+    qc = QCMRF(C, th)
+    p, Z = cf.gibbs_pmf(C, th)
+    H = -(np.log(p) + np.log(Z))
+    for opts in ({}, {"fold_fresh": False}):
+        val, prob = qc.expectation_hamiltonian(be, **opts)
+        assert abs(val - float((p * H).sum())) < 1e-10 and abs(prob - Z / 2 ** 12) < 1e-12
+        st = be.last_engine.stats()["kinds"]["prob"]
+        assert st["launches"] == 1 and st["bytes"] == 16.0 * 2 ** 28      # one read pass, nothing else

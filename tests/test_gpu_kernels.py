@@ -289,6 +289,34 @@ def test_probabilities_norm_and_conditional(lib):
         assert np.abs(full - p).max() < 1e-15
 
 
+@pytest.mark.parametrize("P", [1, 4])
+def test_expect_diag(lib, P):
+    """qsv_expect_diag vs numpy: LDS tables (k <= 12) and wide ones through L2, qubits on shard bits,
+    conditioning mask, deterministic"""
+    n = 16
+    ref = rand_state(n, 31)
+    p = np.abs(ref) ** 2
+    idx = np.arange(2 ** n)
+    rs = np.random.RandomState(7)
+    with lib.Engine(n, devices=(0,) * P) as e:
+        e.set_amplitudes(0, ref)
+        for k in (1, 3, 9, 12, 13, 16):
+            qs = [int(x) for x in rs.permutation(n)[:k]]
+            tab = rs.randn(2 ** k)
+            j = np.zeros_like(idx)
+            for b, q in enumerate(qs):
+                j |= ((idx >> q) & 1) << b
+            got = e.expect_diag(qs, tab)
+            assert abs(got[0] - (p * tab[j]).sum()) < 1e-13 and abs(got[1] - 1.0) < 1e-13
+            assert e.expect_diag(qs, tab) == got
+            fm, fv = (1 << 15) | (1 << 4) | (1 << 9), (1 << 15) | (1 << 9)
+            sel = (idx & fm) == fv
+            got = e.expect_diag(qs, tab, fm, fv)
+            assert abs(got[0] - (p[sel] * tab[j[sel]]).sum()) < 1e-13 and abs(got[1] - p[sel].sum()) < 1e-13
+        with pytest.raises(ValueError):
+            e.expect_diag([1, 1], np.zeros(4))
+
+
 def test_sampling_matches_distribution(lib):
     n = 10
     ref = rand_state(n, 29)

@@ -474,3 +474,28 @@ def test_planner_batches_shard_bit_swaps_into_one_exchange(P):
     e1 = NumpyEngine(14, P)
     program.run_stepwise(e1, pl1.ops)
     assert np.abs(logical_amplitudes(e1, pl1.layout, 14) - cf.amplitudes(C, th)).max() < 1e-13
+
+
+@pytest.mark.parametrize("shards", [1, 4])
+def test_expectation_hamiltonian_host_path(models, shards):
+    """QCMRF.expectation_hamiltonian / expectation_sufficient_statistic through the backend's layout
+    mapping (numpy stand-in engine): <H> in the post-selected state is the Gibbs average of
+    H[x] = -sum_C theta_{C,x_C}; unconditioned it is the plain mean (the variables stay uniform)."""
+    be = QsvBackend(devices=(0,) * shards)
+    be._engine_factory = lambda n, devices=(0,), rank=None, world_size=None: NumpyEngine(n, len(devices))
+    for j in (2, 5):
+        C = models["0.5"]["GRAPHS"][j]
+        th = models["0.5"]["THETAS"][str(j)][4]
+        qc = QCMRF(C, th)
+        p, Z = cf.gibbs_pmf(C, th)
+        H = -(np.log(p) + np.log(Z))                      # p = exp(-H) / Z, independent of the product's own H
+        assert np.abs(H - qc.hamiltonian_diagonal()).max() < 1e-12
+        n = qc.num_vertices
+        for opts in ({}, {"fold_fresh": False}, {"fusion": 0}):
+            val, prob = qc.expectation_hamiltonian(be, **opts)
+            assert abs(val - float((p * H).sum())) < 1e-12 and abs(prob - Z / 2 ** n) < 1e-12
+            val, prob = qc.expectation_hamiltonian(be, post_selected=False, **opts)
+            assert abs(val - H.mean()) < 1e-12 and abs(prob - 1.0) < 1e-12
+        y = (1, 0, 1)[:len(C[-1])]
+        val, prob = qc.expectation_sufficient_statistic(be, C[-1], y)
+        assert abs(val - float((p * qc.sufficient_statistic_diagonal(C[-1], y)).sum())) < 1e-12
