@@ -85,3 +85,135 @@ def test_grid_and_chain_shapes():
     from qcmrf_amd import workloads
     assert workloads.grid(2, 6, 1) == gs.grid_cliques(2, 6, 1) and workloads.chain(10) == gs.chain_cliques(10)
     assert workloads.width(workloads.baseline_config(3)[1]) == 31
+
+
+# ---- Kronecker-product checks of every gate kind: W <= 8, dense matrices built
+# ---- here from np.kron and projectors -- independent of the index arithmetic of the simulators
+def _kron_embed(nq, factors):
+    """tensor product with qubit 0 as the LEAST significant index bit; factors: {qubit: 2x2}"""
+    U = np.eye(1, dtype=np.complex128)
+    for q in range(nq):
+        U = np.kron(factors.get(q, np.eye(2)), U)
+    return U
+
+
+def _kron_controlled(nq, t, M, ctrls=(), vals=None):
+    """I + P_ctrl (x) (M - I)_t with P_ctrl the projector on the control pattern"""
+    vals = [1] * len(ctrls) if vals is None else vals
+    proj = {c: np.diag([1.0 - v, float(v)]) for c, v in zip(ctrls, vals)}
+    return np.eye(2 ** nq) + _kron_embed(nq, {**proj, t: np.asarray(M) - np.eye(2)})
+
+
+def _kron_diag(nq, qubits, table):
+    U = np.zeros((2 ** nq, 2 ** nq), dtype=np.complex128)
+    for j, d in enumerate(np.asarray(table)):
+        U += d * _kron_embed(nq, {q: np.diag([1.0 - ((j >> b) & 1), float((j >> b) & 1)]) for b, q in enumerate(qubits)})
+    return U
+
+
+def _kron_mux(nq, ctrls, t, mats):
+    U = np.zeros((2 ** nq, 2 ** nq), dtype=np.complex128)
+    for j, M in enumerate(mats):
+        U += _kron_embed(nq, {**{q: np.diag([1.0 - ((j >> b) & 1), float((j >> b) & 1)]) for b, q in enumerate(ctrls)}, t: M})
+    return U
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8])
+def test_every_gate_kind_against_kronecker_products(nq):
+    rs = np.random.RandomState(nq)
+    v = rs.randn(2 ** nq) + 1j * rs.randn(2 ** nq)
+    v /= np.linalg.norm(v)
+
+    def ru():
+        return np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))[0]
+
+    def both(U, np_apply, c_apply):
+        """numpy simulator, C simulator and the dense matrix agree on a random state"""
+        want = U @ v
+        assert np.abs(U.conj().T @ U - np.eye(2 ** nq)).max() < 1e-13          # unitary
+        got = v.copy()
+        got = np_apply(got)
+        assert np.abs(got - want).max() < 1e-14
+        r = cref.RefState(nq)
+        r.state[:] = v
+        c_apply(r)
+        assert np.abs(r.state - want).max() < 1e-14
+
+    named = dict(sv.MATS)                                       # h x y z s sdg t tdg sx sxdg ...
+    named.update({"rz": sv.rz(0.37), "rx": sv.rx(-1.1), "ry": sv.ry(2.2), "p": sv.phase(0.9), "u3": sv.u3(0.3, 1.2, -0.7)})
+    for name, M in named.items():
+        for t in {0, nq // 2, nq - 1}:
+            U = _kron_embed(nq, {t: M})
+            both(U, lambda s, t=t, M=M: sv.apply_1q(s, t, M), lambda r, t=t, M=M: r.apply_1q(t, M))
+            assert np.abs(sv.dense_unitary_1q(nq, t, M) - U).max() < 1e-15
+    if nq >= 2:
+        for trial in range(6):                                   # cx / ccx / mcx with +- flags, controlled 2x2, cp / mcphase
+            k = int(rs.randint(1, min(nq - 1, 3) + 1))
+            qs = [int(x) for x in rs.permutation(nq)[:k + 1]]
+            vals = [int(x) for x in rs.randint(0, 2, size=k)]
+            X = sv.MATS["x"]
+            U = _kron_controlled(nq, qs[-1], X, qs[:-1], vals)
+            both(U, lambda s: sv.apply_mcx(s, qs[:-1], qs[-1], vals), lambda r: r.apply_mcx(qs[:-1], qs[-1], vals))
+            M = ru()
+            U = _kron_controlled(nq, qs[-1], M, qs[:-1], vals)
+            both(U, lambda s: sv.apply_1q(s, qs[-1], M, qs[:-1], vals), lambda r: r.apply_1q(qs[-1], M, qs[:-1], vals))
+            assert np.abs(sv.dense_unitary_1q(nq, qs[-1], M, qs[:-1], vals) - U).max() < 1e-15
+            lam = float(rs.uniform(-3, 3))
+            allv = vals + [1]
+            U = _kron_diag(nq, qs, [np.exp(1j * lam) if j == sum(b << e for e, b in enumerate(allv)) else 1.0 for j in range(2 ** (k + 1))])
+            both(U, lambda s: sv.apply_mcphase(s, qs, lam, allv), lambda r: r.apply_mcphase(qs, lam, allv))
+            tab = np.exp(1j * rs.uniform(-3, 3, size=2 ** (k + 1)))
+            U = _kron_diag(nq, qs, tab)
+            both(U, lambda s: sv.apply_diag(s, qs, tab), lambda r: r.apply_diag(qs, tab))
+            mats = np.array([ru() for _ in range(2 ** k)])
+            U = _kron_mux(nq, qs[:-1], qs[-1], mats)
+            both(U, lambda s: sv.apply_mux(s, qs[:-1], qs[-1], mats), lambda r: r.apply_mux(qs[:-1], qs[-1], mats))
+        # dense k-qubit gate (numpy only: the C oracle has none): U_k embedded by index arithmetic of
+        # the TEST, not of apply_kq
+        for k in range(1, min(nq, 4) + 1):
+            qs = [int(x) for x in rs.permutation(nq)[:k]]
+            Uk = np.linalg.qr(rs.randn(2 ** k, 2 ** k) + 1j * rs.randn(2 ** k, 2 ** k))[0]
+            U = np.zeros((2 ** nq, 2 ** nq), dtype=np.complex128)
+            for col in range(2 ** nq):
+                jc = sum(((col >> q) & 1) << b for b, q in enumerate(qs))
+                rest = col & ~sum(1 << q for q in qs)
+                for jr in range(2 ** k):
+                    U[rest | sum(((jr >> b) & 1) << q for b, q in enumerate(qs)), col] = Uk[jr, jc]
+            got = sv.apply_kq(v.copy(), qs, Uk)
+            assert np.abs(got - U @ v).max() < 1e-14
+
+
+def test_gate_inverse_and_diagonal_commutation_properties():
+    """SURVEY.md 4.3 property checks on the numpy simulator: gate . inverse = identity, diagonals
+    commute with each other and with controls, norm is preserved"""
+    nq = 7
+    rs = np.random.RandomState(11)
+    v = rs.randn(2 ** nq) + 1j * rs.randn(2 ** nq)
+    v /= np.linalg.norm(v)
+    s = v.copy()
+    M = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))[0]
+    s = sv.apply_1q(s, 3, M, [0, 5], [1, 0])
+    s = sv.apply_mcx(s, [1, 2], 6, [0, 1])
+    assert abs(np.linalg.norm(s) - 1) < 1e-14
+    s = sv.apply_mcx(s, [1, 2], 6, [0, 1])
+    s = sv.apply_1q(s, 3, M.conj().T, [0, 5], [1, 0])
+    assert np.abs(s - v).max() < 1e-14
+    t1, t2 = np.exp(1j * rs.randn(8)), np.exp(1j * rs.randn(4))
+    a = sv.apply_diag(sv.apply_diag(v.copy(), [0, 3, 6], t1), [3, 4], t2)
+    b = sv.apply_diag(sv.apply_diag(v.copy(), [3, 4], t2), [0, 3, 6], t1)
+    assert np.abs(a - b).max() < 1e-15
+    a = sv.apply_diag(sv.apply_mcx(v.copy(), [0, 3], 5), [0, 3, 6], t1)       # a diagonal on the CONTROLS commutes with the gate
+    b = sv.apply_mcx(sv.apply_diag(v.copy(), [0, 3, 6], t1), [0, 3], 5)
+    assert np.abs(a - b).max() < 1e-15
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """make -C oracle asan: every entry point of qsv_ref.c on small random states under ASan + UBSan
+    (CPU only -- the GPU pool has no sanitizer)"""
+    import os, shutil, subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if shutil.which("make") is None or shutil.which("gcc") is None:
+        pytest.skip("needs make + gcc")
+    r = subprocess.run(["make", "-C", here, "-B", "asan"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan driver ok" in r.stdout
