@@ -67,7 +67,7 @@ def snap(m, tol=4e-16):
 
 class Op:
     __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
-                 "a", "b", "label", "new_pass")
+                 "a", "b", "label", "new_pass", "_sup")
 
     def __init__(self, kind, target=None, ctrls=(), vals=(), qubits=(), mat=None, table=None, mats=None,
                  angle=0.0, mask=0, a=(), b=(), label=""):
@@ -80,18 +80,23 @@ class Op:
         self.a, self.b = a, b
         self.label = label
         self.new_pass = False        # planner hint: this gate opens a new multi-gate pass
+        self._sup = None             # cached support(); whoever re-targets a copied op resets it
 
     def support(self):
-        """every logical qubit the op reads or writes"""
-        if self.kind in ("u", "x"):
-            return tuple(self.ctrls) + (self.target,)
-        if self.kind == "mux":
-            return tuple(self.ctrls) + (self.target,)
-        if self.kind in ("diag", "mcphase", "kq"):
-            return tuple(self.qubits)
-        if self.kind == "swap":
-            return tuple(self.a) + tuple(self.b)
-        return ()
+        """every logical qubit the op reads or writes (cached: the passes ask for it constantly)"""
+        s = self._sup
+        if s is None:
+            k = self.kind
+            if k in ("u", "x", "mux"):
+                s = tuple(self.ctrls) + (self.target,)
+            elif k in ("diag", "mcphase", "kq"):
+                s = tuple(self.qubits)
+            elif k == "swap":
+                s = tuple(self.a) + tuple(self.b)
+            else:
+                s = ()
+            self._sup = s
+        return s
 
     def dense_targets(self):
         """qubits on which the op is NOT diagonal (these must be local to a shard)"""

@@ -550,26 +550,75 @@ def _recover(qubits, U, n_ops):
 _RC = {}
 
 
-def _n_dense_bits(U):
-    """number of window bits in which U is NOT block diagonal: bit b is one iff some nonzero
+def _dense_mask(U):
+    """window bits in which U is NOT block diagonal, as a bit mask: bit b is set iff some nonzero
     entry sits at (r, c) with bit b of r != bit b of c, i.e. iff bit b of OR(r xor c) is set"""
     n = U.shape[0]
     rc = _RC.get(n)
     if rc is None:
         idx = np.arange(n)
         rc = _RC[n] = (idx[:, None] ^ idx[None, :])
-    x = int(np.bitwise_or.reduce(rc[np.abs(U) > _ZERO], initial=0))
-    return bin(x).count("1")
+    return int(np.bitwise_or.reduce(rc[np.abs(U) > _ZERO], initial=0))
+
+
+def _n_dense_bits(U):
+    return bin(_dense_mask(U)).count("1")
+
+
+def _factor_left(U, mask, order=None):
+    """U = (G on window bit b) . M with M block diagonal in b, for one of the (two) dense bits of
+    ``mask``: returns (b, G, M) with M's only dense bit the other one, else None.
+
+    This is what the end of a block looks like in a circuit that went through a transpiler's
+    clean-up passes: the H that closes one CCX on the AND scratch qubit and the H that opens the
+    next have cancelled ACROSS the block boundary (QCMRF.py:225-227 lowered, then merged one-qubit
+    runs), so each block's own gates multiply out to (one-qubit gate) x (multiplexed 2x2) rather than
+    to the multiplexer itself."""
+    n = U.shape[0]
+    for b in (order if order is not None else range(n.bit_length() - 1)):
+        if not (mask >> b) & 1:
+            continue
+        V = U.reshape(n >> (b + 1), 2, 1 << b, n >> (b + 1), 2, 1 << b)      # row (hi, r_b, lo), column (hi', c_b, lo')
+        cols = []
+        for j in (0, 1):                                   # column block j: [g0j M_j ; g1j M_j]
+            A0, A1 = V[:, 0, :, :, j, :], V[:, 1, :, :, j, :]
+            s0, s1 = float(np.vdot(A0, A0).real), float(np.vdot(A1, A1).real)
+            ref, oth, sr = (A0, A1, s0) if s0 >= s1 else (A1, A0, s1)
+            r = np.vdot(ref, oth) / sr
+            if np.abs(oth - r * ref).max() > 1e-12:
+                cols = None
+                break
+            c = np.array([1.0, r]) if s0 >= s1 else np.array([r, 1.0])
+            cols.append(c / np.linalg.norm(c))
+        if cols is None:
+            continue
+        G = np.array(cols).T                               # columns g_.0, g_.1
+        if abs(np.vdot(G[:, 0], G[:, 1])) > 1e-12:
+            continue
+        M = U.copy()
+        W = M.reshape(n >> (b + 1), 2, -1)
+        a0, a1 = W[:, 0].copy(), W[:, 1].copy()
+        Gh = G.conj().T
+        W[:, 0] = Gh[0, 0] * a0 + Gh[0, 1] * a1
+        W[:, 1] = Gh[1, 0] * a0 + Gh[1, 1] * a1
+        rest = _dense_mask(M)
+        if not (rest >> b) & 1 and bin(rest).count("1") <= 1:
+            return b, G, M
+    return None
 
 
 class _DenseWindow:
     def __init__(self):
         self.q, self.pos, self.U, self.ops = [], {}, np.eye(1, dtype=np.complex128), []
-        self.mark = None                 # (n_ops, U copy, qubits) at the last structured point
+        self.mark = None                 # (n_ops, U or M, qubits, carried 1q op or None, target qubit) at the remembered structured point
         self.ndense = None               # cached _n_dense_bits(U); None = stale
+        self.busy = set()                # wires some multi-qubit gate of the window touches
 
     def add(self, op):
-        for q in op.support():
+        sup = op.support()
+        if len(sup) > 1:
+            self.busy.update(sup)
+        for q in sup:
             if q not in self.pos:
                 self.pos[q] = len(self.q)
                 self.q.append(q)
@@ -581,21 +630,98 @@ class _DenseWindow:
                 self.ndense = None
         _op_on_rows(self.U, op, self.pos)
         self.ops.append(op)
-        # a diagonal gate cannot change in which bits U is block diagonal: the structure test is
-        # only repeated after something non-diagonal has acted
         if op.kind not in ("diag", "mcphase"):
             self.ndense = None
-        # blocks of a lowered circuit end on a one-qubit gate: that is where the window may be
-        # exactly a diagonal / multiplexed 2x2 again -- remember the LATEST such point; when the
-        # window overflows it is cut there and the tail starts the next window
-        if len(op.support()) == 1 and len(self.ops) >= 2:
-            if self.ndense is None:
-                self.ndense = _n_dense_bits(self.U)
-            if self.ndense <= 1:
-                self.mark = (len(self.ops), self.U.copy(), list(self.q))
+
+    def consider_mark(self):
+        """Called when the window is about to reach for another qubit -- where one block of a lowered
+        circuit ends and the next begins -- and when it closes.  If what it holds is exactly a
+        diagonal / multiplexed 2x2 right now (possibly times a one-qubit gate on one wire that
+        cancelled across the block boundary, _factor_left), remember the point; should the window
+        overflow later it is cut at the remembered point.  A later point replaces an earlier one
+        unless it only ADDS selects to the same target: that is the next block's first gates
+        leaking in (its CCZ core is diagonal and would ride along), not a bigger block."""
+        if len(self.ops) < 2:
+            return
+        cand = self._candidate(self.U, [])
+        if cand is None:
+            # ... up to the X gates that close its wires (the X that restores a negated control after a
+            # block's last AND, QCMRF.py:224-227): they are the last thing on their wire in the
+            # window, so they commute to behind it
+            last = {}
+            for i, o in enumerate(self.ops):
+                for x in o.support():
+                    last[x] = i
+            tail = []
+            for i in sorted(set(last.values())):
+                o = self.ops[i]
+                if o.kind == "x" and not o.ctrls:
+                    tail.append(i)
+                elif o.kind == "u" and not o.ctrls and abs(o.mat[0, 0]) < 1e-15 and abs(o.mat[1, 1]) < 1e-15:
+                    tail.append(i)
+            if tail and len(tail) < len(self.ops) - 1:
+                U2 = self.U.copy()
+                for i in tail:
+                    qq, m = _as_1q(self.ops[i])
+                    _op_on_rows(U2, ir.op_u(qq, np.asarray(m).conj().T), self.pos)
+                cand = self._candidate(U2, tail)
+        if cand is None:
+            return
+        old = self.mark
+        if old is not None and old[4] is not None and old[4] == cand[4] and len(cand[2]) > len(old[2]) and len(old[2]) >= 3:
+            return
+        self.mark = cand
+
+    def _candidate(self, U, peeled):
+        """(n_ops, M, qubits, carried op, target qubit, peeled op indices) if U is a diagonal / multiplexed
+        2x2, possibly times one one-qubit gate that is carried on to the next window; else None"""
+        dm = _dense_mask(U)
+        nd = bin(dm).count("1")
+        if not peeled:
+            self.ndense = nd
+        if nd <= 1:
+            return (len(self.ops), U.copy() if U is self.U else U, list(self.q), None, self.q[dm.bit_length() - 1] if dm else None, list(peeled))
+        if nd == 2:
+            cnt = [0] * len(self.q)                        # the busier wire first: the AND scratch qubit carries most of a block's gates
+            for o in self.ops:
+                for x in o.support():
+                    cnt[self.pos[x]] += 1
+            f = _factor_left(U, dm, sorted(range(len(self.q)), key=lambda b: -cnt[b]))
+            if f is not None:
+                b, G, M = f
+                rest = dm & ~(1 << b)
+                return (len(self.ops), M, list(self.q), ir.op_u(self.q[b], G, label="carry"), self.q[rest.bit_length() - 1], list(peeled))
+        return None
 
 
 _DENSE_KINDS = ("u", "x", "diag", "mcphase", "mux", "kq")
+
+
+def _components(ops):
+    """ops grouped by the connected components of their qubit supports (order kept inside a group,
+    groups in order of their first op); groups act on disjoint qubits, so they commute"""
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for o in ops:
+        sup = o.support()
+        for q in sup[1:]:
+            parent[find(q)] = find(sup[0])
+        if sup:
+            find(sup[0])
+    groups, order = {}, []
+    for o in ops:
+        sup = o.support()
+        r = find(sup[0]) if sup else None
+        if r not in groups:
+            groups[r] = []
+            order.append(r)
+        groups[r].append(o)
+    return [groups[r] for r in order]
 
 
 def fuse_dense(ops, kmax=5):
@@ -610,21 +736,80 @@ def fuse_dense(ops, kmax=5):
     pos = 0
     win = None
 
-    def flush():
-        """emit the window (up to its last structured point, if it has one); return what is left"""
+    def emit(ops_, q, U):
+        """one window: recovered form if it has one.  A window whose gates fall into several groups
+        of qubits that never interact (say two leftover one-qubit runs, or the tail of one block and
+        the head of the next) is a tensor product: each group is recovered on its own, never
+        multiplied out into one dense gate over all of them"""
+        comps = _components(ops_)
+        if len(comps) > 1:
+            for part in comps:
+                w2 = _DenseWindow()
+                for o in part:
+                    w2.add(o)
+                rec = _recover(w2.q, w2.U, len(part)) if len(part) >= 2 else None
+                out.extend(rec if rec is not None else part)
+            return
+        rec = _recover(q, U, len(ops_)) if len(ops_) >= 2 else None
+        out.extend(rec if rec is not None else ops_)
+
+    def flush(final=False):
+        """emit the window (up to its remembered structured point, if it has one); return what is left"""
         nonlocal win
         if win is None or not win.ops:
             win = None
             return []
         w, win = win, None
-        if w.mark is not None and w.mark[0] < len(w.ops):
-            n, U, q = w.mark
-            rec = _recover(q, U, n)
-            out.extend(rec if rec is not None else w.ops[:n])
+        w.consider_mark()                  # the window as it stands: a block that fills it exactly, or the end of the circuit
+        if final and len(w.ops) >= 2 and (w.mark is None or w.mark[0] < len(w.ops)):
+            if True:
+                # ... up to SOME of the non-diagonal one-qubit gates that close its wires (the X that
+                # restores a negated control after the block's last AND commutes to behind the window;
+                # the H that closes the AND scratch qubit must stay): smallest subsets first
+                last = {}
+                for i, o in enumerate(w.ops):
+                    for x in o.support():
+                        last[x] = i
+                tail = sorted(set(i for x, i in last.items() if w.ops[i].kind in ("u", "x") and not w.ops[i].ctrls))
+                if tail and len(tail) < len(w.ops) - 1:
+                    import itertools
+                    done = False
+                    for r in range(1, len(tail) + 1):
+                        for sub in itertools.combinations(tail, r):
+                            U2 = w.U.copy()
+                            for i in sub:
+                                qq, m = _as_1q(w.ops[i])
+                                _op_on_rows(U2, ir.op_u(qq, np.asarray(m).conj().T), w.pos)
+                            if bin(_dense_mask(U2)).count("1") <= 1:
+                                core = [o for i, o in enumerate(w.ops) if i not in sub]
+                                rec = _recover(w.q, U2, len(core))
+                                out.extend(rec if rec is not None else core)
+                                out.extend(w.ops[i] for i in sub)
+                                done = True
+                                break
+                        if done:
+                            return []
+        if w.mark is not None and (w.mark[0] < len(w.ops) or w.mark[3] is not None or w.mark[5]):
+            n, U, q, carry, _, peeled = w.mark
+            if carry is not None or peeled:               # U has the carried / peeled one-qubit gates divided out already
+                rec = _recover(q, U, n - len(peeled))
+                out.extend(rec if rec is not None else [ir.op_kq(q, U)] if len(q) > 1 else [ir.op_u(q[0], U)])
+                return ([carry] if carry is not None else []) + [w.ops[i] for i in peeled] + w.ops[n:]
+            emit(w.ops[:n], q, U)
             return w.ops[n:]
-        rec = _recover(w.q, w.U, len(w.ops)) if len(w.ops) >= 2 else None
-        out.extend(rec if rec is not None else w.ops)
+        emit(w.ops, w.q, w.U)
         return []
+
+    # One-qubit gates on a wire the window does not hold yet wait outside it (``held``) until a
+    # multi-qubit gate brings their wire in -- then they enter first, in order.  If that never happens
+    # (a leftover X of an earlier block, a wire's closing gate) they commute with everything in the
+    # window and go straight to the output when it closes: they would only hide its structure.
+    held = {}
+
+    def release(keep=()):
+        for q in sorted(held):
+            if q not in keep:
+                out.extend(held.pop(q))
 
     while pos < len(pending):
         op = pending[pos]
@@ -634,26 +819,39 @@ def fuse_dense(ops, kmax=5):
             if rem:
                 pending[pos:pos] = rem
                 continue
+            release()
             out.append(op)
+            pos += 1
+            continue
+        if len(sup) == 1 and (win is None or sup[0] not in win.pos):
+            held.setdefault(sup[0], []).append(op)
             pos += 1
             continue
         if win is not None:
             new = [q for q in sup if q not in win.pos]
+            if new:
+                win.consider_mark()
             if len(win.q) + len(new) > kmax:
                 rem = flush()
+                release(keep=sup)
                 pending[pos:pos] = rem
                 continue
         if win is None:
             win = _DenseWindow()
+        for q in sup:
+            if q not in win.pos:
+                for h in held.pop(q, ()):
+                    win.add(h)
         win.add(op)
         pos += 1
     while True:
-        rem = flush()
+        rem = flush(final=True)
         if not rem:
             break
         win = _DenseWindow()
         for op in rem:
             win.add(op)
+    release()
     return out
 
 
@@ -827,11 +1025,196 @@ def fuse_sandwich(ops):
 
 
 # --------------------------------------------------------------------------------------------
+# helpers for circuits lowered to a basis by a transpiler (run_experiment.py:52)
+# --------------------------------------------------------------------------------------------
+def hoist_leading(ops):
+    """A transpiler emits gates in some topological order of the circuit's DAG: the one-qubit run
+    that opens a wire (the lowered H of QCMRF.py:204-205, merged with whatever one-qubit gates
+    follow it) may sit anywhere before the wire's first two-qubit gate, in the middle of another
+    block's gates.  Nothing has touched the wire before it, so the run commutes to the very front:
+    [one fused 2x2 per hoisted wire] + everything else in its order.
+
+    Hoisted are the wires whose first multi-qubit gate uses them as a CONTROL (or diagonally): a
+    superposed select qubit -- an MRF variable -- whose opening H would otherwise make every window
+    that contains it dense in that qubit.  A wire that starts as a TARGET (the AND scratch qubit, an
+    ancilla) keeps its opening gate where it is: it is part of its block."""
+    lead, rest = split_leading(ops)
+    starts_as_target = set()
+    seen = set()
+    for op in rest:
+        sup = op.support()
+        fresh = [q for q in sup if q not in seen]
+        if fresh:
+            dense = op.dense_targets()
+            starts_as_target.update(q for q in fresh if q in dense)
+            seen.update(fresh)
+    front, keep = [], {}
+    for q in sorted(lead):
+        m = lead[q]
+        if abs(m[0, 1]) < 1e-15 and abs(m[1, 0]) < 1e-15:
+            o = None if (abs(m[0, 0] - 1.0) <= 1e-15 and abs(m[1, 1] - 1.0) <= 1e-15) else ir.op_diag([q], [m[0, 0], m[1, 1]])
+        else:
+            o = ir.op_u(q, m, label="lead")
+        if o is None:
+            continue
+        if q in starts_as_target:
+            keep[q] = o
+        else:
+            front.append(o)
+    if keep:                                   # put a kept opening gate right in front of its wire's first gate
+        body = []
+        for op in rest:
+            for q in op.support():
+                o = keep.pop(q, None)
+                if o is not None:
+                    body.append(o)
+            body.append(op)
+        body.extend(keep[q] for q in sorted(keep))
+        rest = body
+    return front, rest
+
+
+def merge_1q_runs(ops):
+    """consecutive uncontrolled one-qubit gates on a wire (no other gate on that wire in between)
+    -> one 2x2, placed where the run BEGINS (right behind the previous gate on that wire): a
+    transpiler's topological order tends to leave such runs wherever the wire's next two-qubit gate
+    happens to be, far from the block they close.  Exact; a lowered circuit shrinks by a third and
+    the dense windows that follow multiply far fewer matrices."""
+    out, pend, slot = [], {}, {}
+
+    def flush(q):
+        m = pend.pop(q, None)
+        if m is None:
+            return
+        i = slot.pop(q)
+        if abs(m[0, 1]) < 1e-15 and abs(m[1, 0]) < 1e-15:
+            if abs(m[0, 0] - 1.0) > 1e-15 or abs(m[1, 1] - 1.0) > 1e-15:
+                out[i] = Op("diag", qubits=(q,), table=np.array([m[0, 0], m[1, 1]]))
+        elif abs(m[0, 0]) < 1e-15 and abs(m[1, 1]) < 1e-15 and abs(m[0, 1] - 1.0) < 1e-15 and abs(m[1, 0] - 1.0) < 1e-15:
+            out[i] = Op("x", target=q)
+        else:
+            out[i] = Op("u", target=q, mat=m, label="run")
+    for op in ops:
+        q = _1q_qubit(op)
+        if q is not None:
+            k = op.kind
+            cur = pend.get(q)
+            if cur is None:
+                slot[q] = len(out)
+                out.append(None)
+            if k == "diag":
+                t = op.table
+                pend[q] = np.array([[t[0], 0], [0, t[1]]], dtype=np.complex128) if cur is None else \
+                    np.array([[t[0] * cur[0, 0], t[0] * cur[0, 1]], [t[1] * cur[1, 0], t[1] * cur[1, 1]]])
+            else:
+                m = _as_1q(op)[1]
+                pend[q] = np.array(m, dtype=np.complex128) if cur is None else m @ cur
+            continue
+        for x in op.support():
+            flush(x)
+        out.append(op)
+    for q in sorted(pend):
+        flush(q)
+    return [o for o in out if o is not None]
+
+
+def defer_1q(ops):
+    """every uncontrolled one-qubit gate moves FORWARD to just in front of the next gate on its wire
+    (exact: nothing in between touches the wire) -- the opposite of ``merge_1q_runs``' placement,
+    used after the blocks have been re-assembled so that a wire's opening gate (hoisted to the front
+    by ``hoist_leading``) meets the multiplexer it belongs to and ``fuse_mux`` joins them."""
+    out, pend = [], {}
+    for op in ops:
+        q = _1q_qubit(op)
+        if q is not None and q not in pend:
+            pend[q] = op
+            continue
+        for x in op.support():
+            o = pend.pop(x, None)
+            if o is not None:
+                out.append(o)
+        out.append(op)
+    out.extend(pend[q] for q in sorted(pend))
+    return out
+
+
+def _conj_x(op, F):
+    """X_F op X_F for the set F of qubits: control values and table selects on them flip, a 2x2 on
+    such a target has rows and columns swapped.  Returns a new op (or the same if untouched)."""
+    sup = op.support()
+    if not F.intersection(sup):
+        return op
+    k = op.kind
+    if k in ("u", "x"):
+        vals = tuple(v ^ 1 if c in F else v for c, v in zip(op.ctrls, op.vals))
+        if k == "x":
+            return Op("x", target=op.target, ctrls=op.ctrls, vals=vals)
+        m = op.mat[::-1, ::-1] if op.target in F else op.mat
+        return Op("u", target=op.target, ctrls=op.ctrls, vals=vals, mat=np.ascontiguousarray(m), label=op.label)
+    if k == "mcphase":
+        return Op("mcphase", qubits=op.qubits, vals=tuple(v ^ 1 if q in F else v for q, v in zip(op.qubits, op.vals)), angle=op.angle)
+    if k == "diag":
+        flip = sum(1 << e for e, q in enumerate(op.qubits) if q in F)
+        return Op("diag", qubits=op.qubits, table=op.table[np.arange(op.table.size) ^ flip])
+    if k == "mux":
+        flip = sum(1 << e for e, q in enumerate(op.ctrls) if q in F)
+        mats = op.mats[np.arange(op.mats.shape[0]) ^ flip]
+        if op.target in F:
+            mats = mats[:, ::-1, ::-1]
+        return Op("mux", ctrls=op.ctrls, target=op.target, mats=np.ascontiguousarray(mats))
+    if k == "kq":
+        flip = sum(1 << e for e, q in enumerate(op.qubits) if q in F)
+        idx = np.arange(op.mat.shape[0]) ^ flip
+        return Op("kq", qubits=op.qubits, mat=np.ascontiguousarray(op.mat[np.ix_(idx, idx)]))
+    return None
+
+
+def absorb_x(ops):
+    """Plain X gates travel BACKWARDS through the circuit as a frame -- every op they pass is
+    conjugated (controls / selects on the qubit flip) -- until they meet an uncontrolled one-qubit
+    gate on their wire, which swallows them (M -> X M), or another plain X, which they cancel.  A
+    lowered QCMRF circuit is full of them: the +-flag X gates around each AND (QCMRF.py:224-227) are
+    merged and re-ordered by a transpiler so that a block's closing X ends up far from its opening
+    one, which would make the MRF variable qubits look like dense targets.  Afterwards they are what
+    they were in the nested circuit: control values."""
+    F = set()
+    out = []
+    for op in reversed(ops):
+        k = op.kind
+        if k == "x" and not op.ctrls:
+            F ^= {op.target}
+            continue
+        if k == "u" and not op.ctrls and abs(op.mat[0, 0]) < 1e-15 and abs(op.mat[1, 1]) < 1e-15:
+            # anti-diagonal 2x2 = diag(m01, m10) . X: the diagonal stays here, the X travels on
+            t = op.target
+            d = Op("diag", qubits=(t,), table=np.array([op.mat[0, 1], op.mat[1, 0]]))
+            d = _conj_x(d, F) if F else d
+            if abs(d.table[0] - 1.0) > 1e-15 or abs(d.table[1] - 1.0) > 1e-15:
+                out.append(d)
+            F ^= {t}
+            continue
+        if F:
+            if k == "u" and not op.ctrls and op.target in F:
+                F.discard(op.target)
+                op = Op("u", target=op.target, mat=np.ascontiguousarray(op.mat[::-1, :]), label=op.label)    # X . M: rows swapped
+            new = _conj_x(op, F) if F else op
+            if new is None:                                   # an op kind the frame cannot pass: drop the frame here
+                out.extend(Op("x", target=q) for q in sorted(F))
+                F = set()
+            else:
+                op = new
+        out.append(op)
+    out.extend(Op("x", target=q) for q in sorted(F))
+    out.reverse()
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 def _fuse_body(ops, level, kmax, smax, lowered=False, dense_kmax=5):
     head, body = ops[:1], ops[1:]
     if lowered and level >= 3:
         # basis-gate input: re-assemble the blocks first, while the gate order is still pristine
-        body = fuse_dense(body, kmax=dense_kmax)
+        body = defer_1q(fuse_dense(body, kmax=dense_kmax))
     if level >= 2:
         body = fuse_sandwich(body)
     body = fuse_monomial(body, kmax=kmax)
@@ -864,7 +1247,8 @@ def _optimise(ops, level, kmax, smax, dense_kmax=5):
     # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the
     # variable qubits' opening gates stand alone in front and are never dense again, so the
     # ordinary rule applies to it.
-    fused = _fuse_body(fold_init(ops, hold=cands), level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
-    refolded = fold_init(fused[1:])
+    front, rest = hoist_leading(ops)
+    fused = _fuse_body([ir.op_init(0)] + merge_1q_runs(rest), level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
+    refolded = fold_init(absorb_x(front + fused[1:]))
     refolded[0].mask |= fused[0].mask
     return refolded

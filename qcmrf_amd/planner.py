@@ -37,6 +37,7 @@ class Plan:
 
 def _remap(op, lay):
     o = copy.copy(op)
+    o._sup = None
     if op.kind in ("u", "x", "mux"):
         o.target = lay[op.target]
         o.ctrls = tuple(lay[c] for c in op.ctrls)

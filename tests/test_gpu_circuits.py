@@ -670,3 +670,32 @@ def test_expectation_hamiltonian_on_device(be):
         assert abs(val - float((p * H).sum())) < 1e-10 and abs(prob - Z / 2 ** 12) < 1e-12
         st = be.last_engine.stats()["kinds"]["prob"]
         assert st["launches"] == 1 and st["bytes"] == 16.0 * 2 ** 28      # one read pass, nothing else
+
+
+def test_qiskit_shaped_lowered_circuits_on_device(be):
+    """run_experiment.py:52 input as a transpiler's clean-up passes leave it (tests/_qiskit_shapes.py:
+    merged / re-synthesised one-qubit runs in DAG order, cancelled CX and cross-block H pairs, global
+    phase): amplitudes against the closed form on the device at every fusion level, one multiplexer per
+    clique at fusion 3, the generator path with fold_fresh, counts on the support"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _qiskit_shapes import lower_like_qiskit
+    from qcmrf_amd import QCMRF, workloads
+    for C in (workloads.REFERENCE_GRAPHS[3], workloads.chain(8), workloads.grid(2, 4)):        # W = 10, 16, 20
+        n, m, W, dim = cf.model_shape(C)
+        th = random_theta(dim, seed=W)
+        t = lower_like_qiskit(QCMRF(C, th), extra_phase=0.6)
+        want = np.exp(0.6j) * cf.amplitudes(C, th)
+        for opts in ({"fusion": 0}, {"fusion": 2}, {"fusion": 3, "fold_fresh": False}, {"fusion": 3}):
+            if W > 16 and opts["fusion"] == 0:
+                continue
+            amp, meta = run_state(be, t, **opts)
+            assert np.abs(amp - want).max() < 5e-12, (W, opts)
+            if opts["fusion"] == 3:
+                kinds = be.last_engine.stats()["kinds"]
+                assert "kq" not in kinds and meta["n_device_ops"] <= 2 * m + 4, (kinds, meta["n_device_ops"])
+                if opts.get("fold_fresh", True) and W >= 16:
+                    assert set(kinds) == {"init_prod"}, kinds
+        counts = be.run(t, shots=3000, seed_simulator=5).result().get_counts()
+        p = cf.probabilities(C, th)
+        assert sum(counts.values()) == 3000 and all(p[int(k, 2)] > 1e-12 for k in counts)

@@ -499,3 +499,61 @@ def test_expectation_hamiltonian_host_path(models, shards):
         y = (1, 0, 1)[:len(C[-1])]
         val, prob = qc.expectation_sufficient_statistic(be, C[-1], y)
         assert abs(val - float((p * qc.sufficient_statistic_diagonal(C[-1], y)).sum())) < 1e-12
+
+
+def _kinds(ops):
+    k = {}
+    for o in ops:
+        k[o.kind] = k.get(o.kind, 0) + 1
+    return k
+
+
+def test_qiskit_shaped_lowering_helpers_are_exact():
+    """tests/_qiskit_shapes.py: ZSX re-synthesis of one-qubit runs and CX cancellation preserve the
+    unitary including the global phase (checked through the gate-level oracle, fusion 0)"""
+    from _qiskit_shapes import lower_like_qiskit, zsx_synthesis
+    rs = np.random.RandomState(5)
+    for _ in range(50):
+        U = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))[0]
+        seq, g = zsx_synthesis(U)
+        assert [n for n, _ in seq] == ["rz", "sx", "rz", "sx", "rz"]
+    for seed in range(4):
+        qc = rand_circuit(7, 60, 300 + seed)
+        t = lower_like_qiskit(qc, extra_phase=0.37)
+        assert set(t.count_ops()) <= {"cx", "rz", "sx", "x", "measure", "barrier"}
+        amp, ing, pl, _ = run_numpy(t, fusion=0)
+        assert np.abs(amp - np.exp(0.37j) * oracle_state_of(qc)).max() < 1e-12
+
+
+@pytest.mark.parametrize("graph", [2, 3, "chain7", "grid23"])
+def test_qiskit_shaped_lowered_circuits_come_back_as_one_multiplexer_per_clique(models, graph):
+    """What run_experiment.py:52 really feeds the simulator has been through a transpiler's clean-up
+    passes: one-qubit runs re-synthesised as rz sx rz (sx rz) and placed wherever the wire's next CX
+    is, X gates of neighbouring AND blocks merged or cancelled, the H that closes one CCX on the
+    scratch qubit cancelled against the H that opens the next ACROSS clique blocks, a global phase
+    (tests/_qiskit_shapes.py).  Structure recovery must not depend on the tidy gate order of
+    qcmrf_amd.transpile: still ONE multiplexer per (pairwise) clique, variables never dense, the
+    opening H gates folded into the init write; with fold_fresh nothing but init x diagonal factors.
+    (Gate-for-gate equality with a particular Qiskit version's output is parity unpinned: Qiskit is
+    not installable here.)"""
+    from _qiskit_shapes import lower_like_qiskit
+    C = {2: workloads.REFERENCE_GRAPHS[2], 3: workloads.REFERENCE_GRAPHS[3], "chain7": workloads.chain(7),
+         "grid23": workloads.grid(2, 3)}[graph]
+    n, m, W, dim = cf.model_shape(C)
+    th = random_theta(dim, seed=7)
+    qc = QCMRF(C, th)
+    want = cf.amplitudes(C, th)
+    for variant in (dict(merge=True, cancel=True), dict(merge=True, cancel=False), dict(merge=False, cancel=True)):
+        t = lower_like_qiskit(qc, extra_phase=-1.1, **variant)
+        assert len(t.data) > 150 * m and abs(t.global_phase) > 1
+        for fusion in (0, 2, 3):
+            amp, ing, pl, _ = run_numpy(t, fusion=fusion)
+            assert np.abs(amp - np.exp(-1.1j) * want).max() < 1e-11, (variant, fusion)
+        be = QsvBackend()
+        ing, pl = be.compile(t, fold_fresh=False, layout="reference")               # physical = logical qubits
+        k = _kinds(pl.ops)
+        assert k.get("mux", 0) == m and "kq" not in k and "u" not in k and "x" not in k, (variant, k)
+        assert pl.ops[0].kind == "init" and pl.ops[0].mask == (1 << n) - 1          # every variable's H folded into the init write
+        assert all(len(o.ctrls) == 3 for o in pl.ops if o.kind == "mux")            # two variables + the AND scratch qubit
+        ing, pl = be.compile(t)                                                       # fold_fresh: init x diagonal factors only
+        assert set(_kinds(pl.ops)) == {"init", "diag"}, _kinds(pl.ops)
