@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
     ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the reference-layout legs (RCCL / peer-mapped shard-bit exchanges)")
     ap.add_argument("--exchange-deadline", type=float, default=240.0, help="seconds one exchange leg may take before it is abandoned")
+    ap.add_argument("--exchange-child", action="store_true", help=argparse.SUPPRESS)   # internal: run only the exchange legs, print their JSON
     return ap.parse_args()
 
 
@@ -330,6 +331,39 @@ def run_exchange_legs(args, comm, qc, device, world):
     return out
 
 
+def exchange_legs_in_child_processes(args, rank):
+    """Every rank runs the exchange legs in a CHILD process (same RANK / WORLD_SIZE, its own rendezvous
+    endpoint): neither transport has ever seen two GPUs before the driver's scaling run, and a fault,
+    abort or hang down there must not take the already measured line with it.  Rank 0 reads its
+    child's JSON from a pipe; a child that outlives the deadline is killed."""
+    import subprocess
+    env = dict(os.environ)
+    env["QSV_COMM_ENDPOINT"] = "unix:qsv-bench-legs-%s-%s" % (env.get("MASTER_ADDR", "127.0.0.1"), env.get("MASTER_PORT", "29500"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-child", "--gpus", str(args.gpus), "--shots", str(args.shots),
+           "--fusion", str(args.fusion), "--exchange-deadline", str(args.exchange_deadline)]
+    if args.qubits:
+        cmd += ["--qubits", str(args.qubits)]
+    if args.config:
+        cmd += ["--config", str(args.config)]
+    limit = 2 * args.exchange_deadline + 180
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+        try:
+            out, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"rccl_ranks": 0, "error": "the exchange-leg process did not finish within %.0f s and was killed" % limit}
+        lines = [ln for ln in (out or "").strip().splitlines() if ln.startswith("{")]
+        if rank == 0:
+            if lines:
+                return json.loads(lines[-1])
+            return {"rccl_ranks": 0, "error": "the exchange-leg process ended with code %s and no result" % p.returncode}
+        return {"rccl_ranks": 0, "child_returncode": p.returncode}
+    except Exception as e:                                                               # noqa: BLE001
+        return {"rccl_ranks": 0, "error": repr(e)[:300]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -358,6 +392,12 @@ def main():
     name, cliques, theta = workload(args, hbm_total)
     qc = QCMRF(cliques, theta)
     W = qc.num_qubits
+    if args.exchange_child:
+        legs = run_exchange_legs(args, comm, qc, device, world)
+        if rank == 0:
+            print(json.dumps(legs), flush=True)
+        sys.stdout.flush()
+        os._exit(0)                       # a transport may still sit in a device call on some rank
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
                          device=device, devices=(0,) * max(1, args.virtual_shards), fold_fresh=not args.no_fold)
 
@@ -478,7 +518,17 @@ def main():
     exchange_legs = None
     if world > 1 and not args.no_exchange_leg:
         backend.close()                       # its numbers are in; the legs allocate their own shards
-        exchange_legs = run_exchange_legs(args, comm, qc, device, world)
+        if n_dev >= world:
+            exchange_legs = exchange_legs_in_child_processes(args, rank)
+        else:
+            # ranks sharing a GPU (rehearsal on a one-GPU box): a second process per rank would exceed
+            # the box's bound on processes per GPU, and only the peer-mapped transport can run there
+            # anyway (RCCL refuses two ranks on a device and says so): in-process, watchdog only
+            exchange_legs = run_exchange_legs(args, comm, qc, device, world)
+            if exchange_legs.get("abandoned"):
+                if rank == 0:
+                    print(json.dumps({"error": "exchange leg abandoned", "exchange_legs": exchange_legs}), flush=True)
+                os._exit(1)
 
     if rank == 0:
         roof = main_leg["roofline"]
@@ -527,9 +577,6 @@ def main():
             backend.close()
             line["cpu_baseline"] = cpu_baseline(cliques, theta, args.shots, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if exchange_legs is not None and exchange_legs.get("abandoned"):
-        sys.stdout.flush()
-        os._exit(0)               # a transport is stuck in a device call on some rank: nothing left to wait for
     backend.close()
     if world > 1:
         comm.barrier()

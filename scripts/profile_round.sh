@@ -7,6 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 CMD="bench.py --steps 5 --warmup 2 --no-cpu --no-variants"
+cd $ROOT && python3 scripts/mode1_pass.py 20 > /dev/null 2>&1   # (import check before the long runs)
 cd /tmp || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o run -- python3 $ROOT/$CMD > $OUT/prof_$TAG.log 2>&1 || exit 1
 echo "stats done"
@@ -27,6 +28,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_sweeps34_$TAG -o
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sweeps34_$TAG -o run -- python3 $ROOT/$CMD3 > $OUT/pmc_fetch_sweeps34_$TAG.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sweeps34_$TAG -o run -- python3 $ROOT/$CMD3 > $OUT/pmc_write_sweeps34_$TAG.log 2>&1 || exit 1
 echo "sweeps34 done"
+# general-circuit passes: MODE 1 (complex tables, R = 5) and MODE 0 (masked ops, R = 4), 28 qubits
+cd /tmp || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_modes_$TAG -o run -- python3 $ROOT/scripts/mode1_pass.py 28 > $OUT/prof_modes_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_modes_$TAG -o run -- python3 $ROOT/scripts/mode1_pass.py 28 > $OUT/pmc_fetch_modes_$TAG.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_modes_$TAG -o run -- python3 $ROOT/scripts/mode1_pass.py 28 > $OUT/pmc_write_modes_$TAG.log 2>&1 || exit 1
+echo "modes done"
 cd $ROOT
 timeout -k 10 300 python bench.py --gates --steps 20 > $OUT/gates_$TAG.jsonl 2> $OUT/gates_$TAG.err || exit 1
 echo "gates done"

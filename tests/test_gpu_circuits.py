@@ -49,6 +49,10 @@ def test_reference_graphs_amplitudes(be, models, fusion):
 
 
 def test_config1_golden_vector(be, config1):
+    """BASELINE config 1 against tests/golden/config1.json.  That file holds the ORACLE's output
+    (closed form, written by tests/golden/make_golden.py) -- the reference commits no amplitude
+    vector, so this is HIP-vs-oracle at 1e-12, not HIP-vs-reference; the reference's own outputs
+    (10 000-shot Aer counts) pin the same circuit statistically in test_counts_vs_closed_form_and_vs_aer."""
     from qcmrf_amd import QCMRF
     amp, _ = run_state(be, QCMRF(config1["cliques"], config1["theta"]))
     want = np.array(config1["amp_re"]) + 1j * np.array(config1["amp_im"])
