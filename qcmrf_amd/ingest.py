@@ -443,6 +443,121 @@ def _walk(circuit, qmap, cmap, out, depth):
                          "carries no definition" % (name, len(q)))
 
 
+_FLAT_NAMES = frozenset(("rz", "sx", "x", "cx", "id", "measure", "barrier", "delay"))
+_SX = ir.FIXED_1Q["sx"]
+_SX00, _SX01 = complex(_SX[0, 0]), complex(_SX[0, 1])
+_RZ_PHASES = {}
+
+
+def _walk_flat(circuit, out):
+    """A circuit already lowered to the reference's basis {cx, id, rz, sx, x} (run_experiment.py:52) is
+    thousands of one-qubit gates between CX gates.  They are multiplied into ONE 2x2 per run while
+    walking -- four complex numbers per wire, plain Python arithmetic -- and the run is emitted where it
+    BEGINS (right behind the previous gate on its wire): 5.7-7.4 k instructions of the 34-qubit circuit
+    become ~3 k ops without ever existing as 7 k objects.  Exact; used at fusion >= 1 only (fusion 0
+    promises the stream gate by gate).  Returns False (nothing emitted) if the circuit is not flat."""
+    data = circuit.data
+    try:
+        names = [ci.operation.name for ci in data]
+    except AttributeError:
+        return False
+    if not _FLAT_NAMES.issuperset(names):
+        return False
+    qi, ci_map = _bit_maps(circuit)
+    if qi is None:
+        return False
+    ops = out.ops
+    pend, slot = {}, {}                    # wire -> [m00, m01, m10, m11]; wire -> index of its placeholder in ops
+    measured = out._measured
+
+    def flush(q):
+        m = pend.pop(q, None)
+        if m is None:
+            return
+        i = slot.pop(q)
+        m00, m01, m10, m11 = m
+        if m01 == 0 and m10 == 0:
+            if m00 != 1 or m11 != 1:
+                ops[i] = ir.Op("diag", qubits=(q,), table=np.array([m00, m11], dtype=np.complex128))
+        elif m00 == 0 and m11 == 0 and m01 == 1 and m10 == 1:
+            ops[i] = ir.Op("x", target=q)
+        else:
+            ops[i] = ir.Op("u", target=q, mat=np.array([[m00, m01], [m10, m11]], dtype=np.complex128), label="run")
+
+    out.global_phase += float(getattr(circuit, "global_phase", 0.0) or 0.0)
+    n_src = 0
+    conds = [ci.operation for ci in data if getattr(ci.operation, "condition", None) is not None]
+    if conds:
+        raise ValueError("classically conditioned operation %r is not supported" % conds[0].name)
+    pget = pend.get
+    for ci, name in zip(data, names):
+        if name == "rz" or name == "sx" or name == "x":
+            q = qi[id(ci.qubits[0])]
+            if measured and q in measured:
+                raise ValueError("gate %r acts on qubit %d after it was measured; mid-circuit measurement "
+                                 "with later use of the qubit is not supported" % (name, q))
+            n_src += 1
+            m = pget(q)
+            if m is None:
+                m = pend[q] = [1, 0, 0, 1]
+                slot[q] = len(ops)
+                ops.append(None)
+            if name == "rz":
+                lam = ci.operation.params[0]
+                ph = _RZ_PHASES.get(lam)
+                if ph is None:
+                    try:
+                        f = float(lam)
+                    except TypeError:
+                        raise ValueError("unbound or non-numeric parameter %r in gate 'rz'" % (lam,))
+                    if len(_RZ_PHASES) > 4096:
+                        _RZ_PHASES.clear()
+                    e = np.exp(0.5j * f)
+                    ph = _RZ_PHASES[lam] = (complex(e.conjugate()), complex(e))
+                e0, e1 = ph
+                m[0] *= e0
+                m[1] *= e0
+                m[2] *= e1
+                m[3] *= e1
+            elif name == "sx":
+                a, b, c, d = m
+                m[0] = _SX00 * a + _SX01 * c
+                m[1] = _SX00 * b + _SX01 * d
+                m[2] = _SX01 * a + _SX00 * c
+                m[3] = _SX01 * b + _SX00 * d
+            else:                                        # x: rows swapped
+                m[0], m[1], m[2], m[3] = m[2], m[3], m[0], m[1]
+            continue
+        if name == "cx":
+            qs = ci.qubits
+            q, t = qi[id(qs[0])], qi[id(qs[1])]
+            if measured and (q in measured or t in measured):
+                raise ValueError("gate 'cx' acts on qubit %d after it was measured; mid-circuit measurement "
+                                 "with later use of the qubit is not supported" % (q if q in measured else t))
+            n_src += 1
+            flush(q)
+            flush(t)
+            ops.append(ir.Op("x", target=t, ctrls=(q,), vals=(1,)))
+            continue
+        if name == "measure":
+            q = qi[id(ci.qubits[0])]
+            n_src += 1
+            flush(q)
+            c = ci_map[id(ci.clbits[0])]
+            out.measure[c] = q
+            measured.add(q)
+            if out.keep_measures:
+                ops.append(ir.Op("measure", target=q, mask=c))
+            continue
+        if name == "id":
+            n_src += 1
+    for q in sorted(pend):
+        flush(q)
+    out.ops = [o for o in ops if o is not None]
+    out.n_source_ops += n_src
+    return True
+
+
 def ingest(circuit, peephole=False, keep_measures=False):
     """peephole=True additionally folds X..X . MCX . X..X definitions (Qiskit's AND with negative
     flags) into one MCX with negated controls while walking -- exact, and 5x fewer ops to fuse."""
@@ -452,7 +567,8 @@ def ingest(circuit, peephole=False, keep_measures=False):
     out.peephole = bool(peephole)
     out.keep_measures = bool(keep_measures)
     out._measured = set()
-    _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
+    if not (peephole and not keep_measures and _walk_flat(circuit, out)):
+        _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
     cregs = getattr(circuit, "cregs", None)
     if cregs:
         out.creg_sizes = [(getattr(r, "name", "c"), len(r)) for r in cregs]

@@ -1027,7 +1027,7 @@ def fuse_sandwich(ops):
 # --------------------------------------------------------------------------------------------
 # helpers for circuits lowered to a basis by a transpiler (run_experiment.py:52)
 # --------------------------------------------------------------------------------------------
-def hoist_leading(ops):
+def hoist_leading(ops, split=None):
     """A transpiler emits gates in some topological order of the circuit's DAG: the one-qubit run
     that opens a wire (the lowered H of QCMRF.py:204-205, merged with whatever one-qubit gates
     follow it) may sit anywhere before the wire's first two-qubit gate, in the middle of another
@@ -1038,7 +1038,7 @@ def hoist_leading(ops):
     superposed select qubit -- an MRF variable -- whose opening H would otherwise make every window
     that contains it dense in that qubit.  A wire that starts as a TARGET (the AND scratch qubit, an
     ancilla) keeps its opening gate where it is: it is part of its block."""
-    lead, rest = split_leading(ops)
+    lead, rest = split if split is not None else split_leading(ops)
     starts_as_target = set()
     seen = set()
     for op in rest:
@@ -1087,6 +1087,10 @@ def merge_1q_runs(ops):
         if m is None:
             return
         i = slot.pop(q)
+        single = keep.pop(q, None)
+        if single is not None:
+            out[i] = single
+            return
         if abs(m[0, 1]) < 1e-15 and abs(m[1, 0]) < 1e-15:
             if abs(m[0, 0] - 1.0) > 1e-15 or abs(m[1, 1] - 1.0) > 1e-15:
                 out[i] = Op("diag", qubits=(q,), table=np.array([m[0, 0], m[1, 1]]))
@@ -1094,6 +1098,7 @@ def merge_1q_runs(ops):
             out[i] = Op("x", target=q)
         else:
             out[i] = Op("u", target=q, mat=m, label="run")
+    keep = {}                              # wire -> the single op of a run of length one (re-emitted untouched)
     for op in ops:
         q = _1q_qubit(op)
         if q is not None:
@@ -1102,6 +1107,9 @@ def merge_1q_runs(ops):
             if cur is None:
                 slot[q] = len(out)
                 out.append(None)
+                keep[q] = op
+            else:
+                keep.pop(q, None)
             if k == "diag":
                 t = op.table
                 pend[q] = np.array([[t[0], 0], [0, t[1]]], dtype=np.complex128) if cur is None else \
@@ -1110,8 +1118,10 @@ def merge_1q_runs(ops):
                 m = _as_1q(op)[1]
                 pend[q] = np.array(m, dtype=np.complex128) if cur is None else m @ cur
             continue
-        for x in op.support():
-            flush(x)
+        if pend:
+            for x in op.support():
+                if x in pend:
+                    flush(x)
         out.append(op)
     for q in sorted(pend):
         flush(q)
@@ -1247,7 +1257,7 @@ def _optimise(ops, level, kmax, smax, dense_kmax=5):
     # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the
     # variable qubits' opening gates stand alone in front and are never dense again, so the
     # ordinary rule applies to it.
-    front, rest = hoist_leading(ops)
+    front, rest = hoist_leading(ops, split=(lead, rest))
     fused = _fuse_body([ir.op_init(0)] + merge_1q_runs(rest), level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
     refolded = fold_init(absorb_x(front + fused[1:]))
     refolded[0].mask |= fused[0].mask

@@ -13,7 +13,10 @@ def ru():
 eng = _lib.Engine(W)
 eng.init_uniform((1 << W) - 1)
 eng.set_option("pass_budget", 0)
-tg = [8, 9, 10, 11]
+import os
+RR = int(os.environ.get("QSV_R", "4"))
+eng.set_option("multi_r", RR)
+tg = [8, 9, 10, 11][:RR]
 def run(ops, label):
     rec, data = program.encode(ops)
     for _ in range(2): eng.exec(rec, data)
@@ -24,22 +27,23 @@ def run(ops, label):
     nl = sum(v["launches"] for v in st["kinds"].values()) / 4
     print("%-40s ops %3d  launches/exec %.1f  %.3f ms/exec  %5.1f us/op  %4.0f GB/s" % (label, len(ops), nl, ms, ms * 1e3 / len(ops), 32 * 2.0 ** W * nl / ms / 1e6), flush=True)
     return ms
-import os
-for xf in (() if os.environ.get("QSV_STREAM_ONLY") else (1, 0)):
+for xf in (() if os.environ.get("QSV_STREAM_ONLY") else ((0,) if os.environ.get("QSV_MICRO_ONLY") else (1, 0))):
     eng.set_option("xframe", xf)
     print("--- xframe", xf)
     for N in (4, 16, 32, 60):
-        run([ir.op_x(tg[i % 4]) for i in range(N)], "plain X round-robin")
-        run([ir.op_x(tg[i % 4], [2, 3], [1, 0]) for i in range(N)], "CCX (lane-bit controls)")
-        run([ir.op_x(tg[i % 4], [tg[(i + 1) % 4], tg[(i + 2) % 4]], [1, 0]) for i in range(N)], "CCX (register controls)")
-        run([ir.op_x(tg[i % 4], [20, 21], [1, 0]) for i in range(N)], "CCX (block-bit controls)")
-        run([ir.op_u(tg[i % 4], ru()) for i in range(N)], "dense 2x2 (type 2)")
-        run([ir.op_u(tg[i % 4], ru(), [3], [1]) for i in range(N)], "controlled 2x2 (lane control)")
-        run([ir.op_mcphase([2, tg[i % 4]], 0.3) for i in range(N)], "cp (lane + register)")
-        run([ir.op_mcphase([tg[(i + 1) % 4], tg[i % 4]], 0.3) for i in range(N)], "cp (register + register)")
-        run([ir.op_mux([2, tg[(i + 1) % 4]], tg[i % 4], np.array([ru() for _ in range(4)])) for i in range(N)], "mux, register select")
-        run([ir.op_diag([2, tg[i % 4]], np.exp(1j * rs.randn(4))) for i in range(N)], "diag, register select")
+        run([ir.op_x(tg[i % RR]) for i in range(N)], "plain X round-robin")
+        run([ir.op_x(tg[i % RR], [2, 3], [1, 0]) for i in range(N)], "CCX (lane-bit controls)")
+        run([ir.op_x(tg[i % RR], [tg[(i + 1) % RR], tg[(i + 2) % RR]], [1, 0]) for i in range(N)], "CCX (register controls)")
+        run([ir.op_x(tg[i % RR], [20, 21], [1, 0]) for i in range(N)], "CCX (block-bit controls)")
+        run([ir.op_u(tg[i % RR], ru()) for i in range(N)], "dense 2x2 (type 2)")
+        run([ir.op_u(tg[i % RR], ru(), [3], [1]) for i in range(N)], "controlled 2x2 (lane control)")
+        run([ir.op_mcphase([2, tg[i % RR]], 0.3) for i in range(N)], "cp (lane + register)")
+        run([ir.op_mcphase([tg[(i + 1) % RR], tg[i % RR]], 0.3) for i in range(N)], "cp (register + register)")
+        run([ir.op_mux([2, tg[(i + 1) % RR]], tg[i % RR], np.array([ru() for _ in range(4)])) for i in range(N)], "mux, register select")
+        run([ir.op_diag([2, tg[i % RR]], np.exp(1j * rs.randn(4))) for i in range(N)], "diag, register select")
 eng.close()
+if os.environ.get("QSV_MICRO_ONLY"):
+    sys.exit(0)
 # the reference stream, gate by gate, at this width
 from qcmrf_amd import QCMRF, workloads as wl
 from qcmrf_amd.backend import QsvBackend
