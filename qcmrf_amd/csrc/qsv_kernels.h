@@ -692,13 +692,17 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
     }
   } else if (op.nlist) {   // type 2, plain X (CX / CCX / MCX with +-flags): a masked register swap, no flops
     const bool ct = (base & op.tmask) == op.tval;
+    // Masked register swap: eight selects per pair where the lane / block controls decide (an
+    // exec-masked v_swap_b32 version was tried: the compiler copies both operands first, 12
+    // instructions per pair).  The register part of the condition is wave-uniform (j0 is a
+    // compile-time constant): a REAL scalar branch skips the pairs it rules out -- a CCX with both
+    // controls on register bits touches a quarter of the tile; the empty asm keeps the compiler
+    // from turning the branch back into 2^R selects.
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-      // the register part of the condition is wave-uniform (j0 is a compile-time constant): a scalar
-      // branch skips the pairs it rules out -- CCX with both controls on register bits touches a
-      // quarter of the tile -- and only the lane / block part costs selects
       if (((unsigned)j0 & op.rmask) == op.rval) {
+        asm volatile("" ::);
         const cplx x = a[j0], y = a[j1];
         a[j0] = make_double2(ct ? y.x : x.x, ct ? y.y : x.y);
         a[j1] = make_double2(ct ? x.x : y.x, ct ? x.y : y.y);
@@ -844,7 +848,10 @@ __device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op,
     const cplx ph = make_double2(ct ? op.m[0] : 1.0, ct ? op.m[1] : 0.0);
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j)
-      if (((unsigned)j & op.rmask) == op.rval) a[j] = cmul(a[j], ph);
+      if (((unsigned)j & op.rmask) == op.rval) {
+        asm volatile("" ::);                               // a real scalar branch: do not if-convert into 2^R multiplies + selects
+        a[j] = cmul(a[j], ph);
+      }
   }
 }
 
