@@ -254,10 +254,18 @@ class QuantumCircuit:
     def inverse(self):
         inv = QuantumCircuit(self.num_qubits, self.num_clbits, name=self.name + "_dg",
                              global_phase=-self.global_phase)
+        inverted = {}                    # instructions that share one definition share its inverse too
         for ci in reversed(self.data):
             qs = [inv.qubits[self._qindex[id(q)]] for q in ci.qubits]
             cs = [inv.clbits[self._cindex[id(c)]] for c in ci.clbits]
-            inv._add(ci.operation.inverse(), qs, cs)
+            op = ci.operation
+            if op.definition is not None:
+                d = inverted.get(id(op.definition))
+                if d is None:
+                    d = inverted[id(op.definition)] = op.definition.inverse()
+                inv._add(Instruction(op.name + "_dg", op.num_qubits, op.num_clbits, op.params, d), qs, cs)
+            else:
+                inv._add(op.inverse(), qs, cs)
         return inv
 
 

@@ -292,7 +292,8 @@ def _block_of_key(key):
         ys.append(sum(v << e for e, v in enumerate(sa[1])))
     if ok and wires is not None:
         kk = len(wires[0])
-        res = (wires[0], wires[1], wires[2], np.stack([_phase_mask(kk, y) for y in ys], axis=1))
+        n_src = n // 3 + sum(len(and_keys[k][0]) for k in range(0, n, 3)) + sum(len(and_keys[k][0]) for k in range(2, n, 3))
+        res = (wires[0], wires[1], wires[2], np.stack([_phase_mask(kk, y) for y in ys], axis=1), n_src)
     if len(_BLOCKS) > 1024:
         _BLOCKS.clear()
     _BLOCKS[key] = res
@@ -321,6 +322,7 @@ def _emit_phase_block(definition, qmap, out):
         if getattr(p, "condition", None) is not None or getattr(p, "ctrl_state", None) not in (None, 1):
             return False
     and_keys = []
+    prev_d = prev_k = None
     for k, o in enumerate(ops):
         if k % 3 == 1:
             and_keys.append(None)
@@ -328,9 +330,10 @@ def _emit_phase_block(definition, qmap, out):
         d = getattr(o, "definition", None)
         if d is None or getattr(o, "condition", None) is not None:
             return False
-        ak = _and_key(d)
+        ak = prev_k if d is prev_d else _and_key(d)         # compute / uncompute often share one definition object
         if ak is None:
             return False
+        prev_d, prev_k = d, ak
         and_keys.append(ak)
     qi = {id(b): i for i, b in enumerate(qs)}
     key = (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]),
@@ -338,15 +341,18 @@ def _emit_phase_block(definition, qmap, out):
     blk = _block_of_key(key)
     if blk is None:
         return False
-    ctrls, tgt, other, M = blk
+    ctrls, tgt, other, M, n_src = blk
     glob = [qmap[x] for x in ctrls]
     glob.append(qmap[tgt])
     glob.append(qmap[other])
     if out._measured and out._measured.intersection(glob):
         return False
-    ang = M @ np.array([_fparams(p)[0] for p in ops[1::3]], dtype=np.float64)
-    out.ops.append(ir.Op("diag", qubits=tuple(glob), table=np.exp(1j * ang)))
-    out.n_source_ops += n // 3 + sum([len(ops[k].definition.data) for k in range(0, n, 3)]) + sum([len(ops[k].definition.data) for k in range(2, n, 3)])
+    # the table is exp(i M lambda); the exponentials of ALL blocks of a circuit are taken in one call
+    # when the walk is over (ingest -> _finish_phase_blocks)
+    op = ir.Op("diag", qubits=tuple(glob), table=None)
+    out.ops.append(op)
+    out._phase_blocks.append((op, M, [_fparams(p)[0] for p in ops[1::3]]))
+    out.n_source_ops += n_src
     return True
 
 
@@ -394,8 +400,13 @@ def _walk(circuit, qmap, cmap, out, depth):
     cache = {}
     out.global_phase += float(getattr(circuit, "global_phase", 0.0) or 0.0)
     qi, ci_map = _bit_maps(circuit)
-    for ci in circuit.data:
-        op, qargs, cargs = _unpack(ci)
+    data = circuit.data
+    try:
+        triples = [(ci.operation, ci.qubits, ci.clbits) for ci in data]
+    except AttributeError:                                   # legacy (op, qargs, cargs) tuples
+        triples = [_unpack(ci) for ci in data]
+    primitives = _PRIMITIVES
+    for op, qargs, cargs in triples:
         if qi is not None:
             q = [qmap[qi[id(b)]] for b in qargs]
         else:
@@ -419,10 +430,10 @@ def _walk(circuit, qmap, cmap, out, depth):
         if touched:
             raise ValueError("gate %r acts on qubit %d after it was measured; mid-circuit measurement "
                              "with later use of the qubit is not supported" % (name, sorted(touched)[0]))
-        handler = _PRIMITIVES.get(name)
+        handler = primitives.get(name)
         if handler is None and "_o" in name:              # Qiskit open-control naming: ccx_o1 ...
             m = _OPEN_CTRL.match(name)
-            handler = _PRIMITIVES.get(m.group(1)) if m else None
+            handler = primitives.get(m.group(1)) if m else None
         if handler is not None:
             handler(out.ops, op, q)
             out.n_source_ops += 1
@@ -567,10 +578,26 @@ def ingest(circuit, peephole=False, keep_measures=False):
     out.peephole = bool(peephole)
     out.keep_measures = bool(keep_measures)
     out._measured = set()
+    out._phase_blocks = []
     if not (peephole and not keep_measures and _walk_flat(circuit, out)):
         _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
+    _finish_phase_blocks(out)
     cregs = getattr(circuit, "cregs", None)
     if cregs:
         out.creg_sizes = [(getattr(r, "name", "c"), len(r)) for r in cregs]
     del out._measured
     return out
+
+
+def _finish_phase_blocks(out):
+    """tables of the recognised phase blocks: angle vectors of all blocks, ONE exp over them all"""
+    blocks = out._phase_blocks
+    del out._phase_blocks
+    if not blocks:
+        return
+    angs = [M @ np.asarray(lam, dtype=np.float64) for _, M, lam in blocks]
+    tab = np.exp(1j * np.concatenate(angs))
+    off = 0
+    for (op, _, _), a in zip(blocks, angs):
+        op.table = tab[off:off + a.size]
+        off += a.size

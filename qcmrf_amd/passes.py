@@ -76,7 +76,7 @@ def _is_hlike(m):
     return abs(abs(m[0, 0]) - SQH) < 1e-15 and abs(abs(m[1, 0]) - SQH) < 1e-15
 
 
-def fold_init(ops, hold=None):
+def fold_init(ops, hold=None, split=None):
     """[init(mask)] + remaining ops.
 
     A leading one-qubit gate that maps |0> to an equal-weight superposition (H, or its lowered
@@ -86,7 +86,7 @@ def fold_init(ops, hold=None):
     variable qubits fold (QCMRF.py:204-205), an ancilla's opening H (QCMRF.py:231) does not: it
     fuses into the ancilla's own multiplexer anyway, and keeping the ancilla in |0> until then is
     what lets the engine skip the still-empty part of the vector (zero tracking)."""
-    lead, rest = split_leading(ops)
+    lead, rest = split if split is not None else split_leading(ops)
     if hold is None:
         hold = set(q for op in rest for q in op.dense_targets())
     fold = set(q for q, m in lead.items() if q not in hold and _is_hlike(m))
@@ -1251,7 +1251,7 @@ def _optimise(ops, level, kmax, smax, dense_kmax=5):
     cands = set(q for q, m in lead.items() if _is_hlike(m))
     hold0 = set(q for op in rest for q in op.dense_targets()) & cands
     if level < 3 or hold0 != cands or not cands:
-        return _fuse_body(fold_init(ops, hold=hold0), level, kmax, smax, dense_kmax=dense_kmax)
+        return _fuse_body(fold_init(ops, hold=hold0, split=(lead, rest)), level, kmax, smax, dense_kmax=dense_kmax)
     # every candidate looks dense in the raw stream: a circuit lowered to basis gates, where even
     # pure select qubits are CX targets inside decompositions (and a CCX opens with rz-sx-rz on
     # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the

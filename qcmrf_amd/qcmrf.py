@@ -158,9 +158,10 @@ class QCMRF(QuantumCircuit):
             if np.isclose(g, 0):
                 continue
             flags = (np.array(y) * 2 - 1).tolist()
-            sub.append(AND(len(C), flags), wires)
+            conj = AND(len(C), flags)                      # compute and uncompute are the same gate (QCMRF.py:225,227)
+            sub.append(conj, wires)
             sub.cp(2 * g, n, n + 1)
-            sub.append(AND(len(C), flags), wires)
+            sub.append(conj, wires)
         return sub
 
     def _build(self):
