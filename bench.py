@@ -408,6 +408,7 @@ def main():
     variants = {}
 
     def leg(name, n, circuit=None, **opts):
+        backend.run(circuit or qc, shots=args.shots, seed_simulator=76, **opts)       # one untimed warm-up run
         comm.barrier()
         t0 = time.perf_counter()
         agg = {}
