@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqsv.so")
+LIB_PATH = os.environ.get("QSV_LIBRARY") or os.path.join(_HERE, "csrc", "libqsv.so")   # QSV_LIBRARY: kernel experiments (scripts/)
 
 MAX_CTRL = 16
 MAX_KQ = 5
@@ -23,10 +23,10 @@ K_NAMES = ["init", "1q", "x", "diag", "mcphase", "mux", "kq", "prob", "swap", "e
 K_COUNT = len(K_NAMES)
 
 # defaults of the qsv_set_option knobs (qsv.hip: struct qsv_handle), so that a per-run override can be undone
-OPTION_DEFAULTS = {"blocks_per_cu": 1 << 16, "unroll": 4, "lowt_shuffle": 1, "nontemporal": 0, "lane_targets": 1,
+OPTION_DEFAULTS = {"blocks_per_cu": 1 << 16, "unroll": 4, "lowt_shuffle": 1, "nontemporal": -1, "lane_targets": 1,
                    "cache_sums": 1, "fused_sums": 1, "pair_variant": 0, "kq_mfma": 1, "zero_tracking": 0, "lane_map": 1,
                    "init_prod_bit0": 0, "init_prod_r": 0, "init_prod": 1, "pass_hints": 1, "dyn_lanes": 3, "multi_r": 5,
-                   "exchange_chunk_log2": 24, "xframe": 1, "pass_budget": 0}
+                   "exchange_chunk_log2": 24, "xframe": 1, "pass_budget": 0, "multi_nt": -1, "init_prod_nt": -1}
 
 OP_INIT_ZERO, OP_INIT_UNIFORM, OP_1Q, OP_MCX, OP_DIAG, OP_MCPHASE, OP_MUX, OP_KQ, OP_SWAP = range(9)
 OPF_NEW_PASS = 1

@@ -175,7 +175,7 @@ struct qsv_handle {
   int opt_blocks_per_cu = 1 << 16;  // measured on MI355X: one tile per workgroup (no grid-stride) streams fastest
   int opt_unroll = 4;
   int opt_lowt_shuffle = 1;
-  int opt_nt = 0;
+  int opt_nt = -1;                    // one-gate sweeps non-temporal: -1 by shard size and bit positions (single_nt), 0 never, 1 always
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
   int opt_pair_variant = 0;           // experiments: see run_single
   int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
@@ -189,6 +189,8 @@ struct qsv_handle {
   int opt_fused_sums = 1;             // last k_multi pass of a program also leaves the per-tile |amp|^2 sums
   int opt_kq_mfma = 1;                // dense k >= 3 gates on the f64 matrix cores
   int opt_zero_tracking = 0;          // opt-in: skip the part of the shard that is provably still zero
+  int opt_multi_nt = -1;              // k_multi with non-temporal loads + stores: -1 shards of >= 2^26 amplitudes, 0 never, 1 always
+  int opt_init_prod_nt = -1;          // generator with non-temporal stores: -1 by shard size, 0 never, 1 always
   int opt_xframe = 1;                 // uncontrolled X gates inside a pass become an XOR on its store addresses
   int opt_pass_budget = 0;            // opt-in cap on the arithmetic of a general pass, percent of one read+write of the shard (0: none)
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)

@@ -384,6 +384,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // sums[b] = sum |amp|^2 over block b (fixed-order tree: deterministic)
+template <bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_blocksum(const cplx* __restrict__ amp, uint64_t n,
                                                       double* __restrict__ sums, uint64_t nblocks) {
   __shared__ double part[QSV_TPB / 64];
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_blocksum(const cplx* __restrict__ a
 #pragma unroll 4
     for (int k = 0; k < QSV_SBLOCK / QSV_TPB; ++k) {
       const uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
-      if (i < n) { const cplx a = amp[i]; s = fma(a.x, a.x, fma(a.y, a.y, s)); }
+      if (i < n) { const cplx a = NT ? ld_nt(amp + i) : amp[i]; s = fma(a.x, a.x, fma(a.y, a.y, s)); }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
 // partial[2b+1] = sum |amp|^2 over the same indices (the conditioning mass), one pair per workgroup
 // in a fixed order (deterministic).  One read pass: 16 B per amplitude, HBM bound.
 // H = -sum theta Phi of QCMRF.py:181-193 is such an observable on the n variable qubits.
-template <bool LDS>
+template <bool LDS, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict__ amp, uint64_t n, uint64_t hi, BitList q,
                                                          uint64_t fmask, uint64_t fval, const double* __restrict__ table,
                                                          int ntab, double* __restrict__ partial) {
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t i = base + (uint64_t)u * QSV_TPB;
-      a[u] = i < n ? amp[i] : make_double2(0.0, 0.0);
+      a[u] = i < n ? (NT ? ld_nt(amp + i) : amp[i]) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -881,7 +882,10 @@ __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __r
 // (amp = val where (index & nonmask) == 0): the init write and the first gate pass become one.
 // SIMPLE: every op of the pass is a table op whose select bits are all lane/block bits (the
 // shape of a fused QCMRF circuit): the general paths are compiled out.
-template <int R, bool INIT, int MODE>
+// NT: non-temporal loads AND stores of the amplitudes (measured on MI355X, profiles/r02_nt_variants.log:
+// either alone gains 1-2 %, both together 9 % on a 4 GiB shard -- 5.93 -> 6.50 TB/s -- and 3 % on a
+// 256 GiB one; a shard that fits the caches keeps the plain form)
+template <int R, bool INIT, int MODE, bool NT>
 __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cplx* __restrict__ amp, uint64_t nthreads,
                                                    BitIns ins, RegPos rp, LanePos lp,
                                                    const MultiOp* __restrict__ ops,
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
       uint64_t off = 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-      a[j] = (pblk + off)[base_thr];
+      a[j] = NT ? ld_nt((pblk + off) + base_thr) : (pblk + off)[base_thr];
     }
   } else {
 #pragma unroll
@@ -964,7 +968,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
 #pragma unroll
       for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
       if ((unsigned)j & zreg) a[j] = make_double2(0.0, 0.0);
-      else a[j] = (pblk + off)[base_thr];
+      else a[j] = NT ? ld_nt((pblk + off) + base_thr) : (pblk + off)[base_thr];
     }
   }
   constexpr int NS = R + 1;
@@ -996,7 +1000,8 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     uint64_t off = 0;
 #pragma unroll
     for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
-    (pst + (off ^ xreg))[thr_st] = a[j];
+    if (NT) st_nt((pst + (off ^ xreg)) + thr_st, a[j]);
+    else (pst + (off ^ xreg))[thr_st] = a[j];
     psum = fma(a[j].x, a[j].x, fma(a[j].y, a[j].y, psum));
   }
   // last pass of a program: leave sum |amp|^2 of this workgroup's tile behind, so that measurement
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_fill_zero(cplx* __restrict__ amp, u
 // ---------------------------------------------------------------------------------------
 typedef double __attribute__((ext_vector_type(4))) f64x4;
 
-template <int K>
+template <int K, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uint64_t nbatch,
                                                      BitIns ins, KqOffs offs,
                                                      const double* __restrict__ ur,
@@ -1157,7 +1162,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
     const uint64_t base = ins_bits(bt * 16 + jcol, ins);
     cplx v[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) v[ks] = amp[base | offs.off[ks * 4 + kq]];
+    for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | offs.off[ks * 4 + kq])) : amp[base | offs.off[ks * 4 + kq]];
     f64x4 dre[MB], dim[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -1179,7 +1184,8 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        amp[base | offs.off[mb * 16 + kq + 4 * r]] = make_double2(dre[mb][r], dim[mb][r]);
+        if (NT) st_nt(amp + (base | offs.off[mb * 16 + kq + 4 * r]), make_double2(dre[mb][r], dim[mb][r]));
+        else amp[base | offs.off[mb * 16 + kq + 4 * r]] = make_double2(dre[mb][r], dim[mb][r]);
   }
 }
 

@@ -74,7 +74,9 @@ def run(n_cases=300, seed=7, verbose=True):
         opts = {"multi_r": int(rs.choice([5, 5, 5, 4, 6, 3])), "dyn_lanes": int(rs.choice([3, 3, 0, 1, 2])),
                 "lane_map": int(rs.choice([1, 1, 0])), "lane_targets": int(rs.choice([1, 1, 1, 0])),
                 "zero_tracking": int(rs.choice([0, 0, 0, 1])), "init_prod": int(rs.choice([1, 1, 0])),
-                "pass_hints": int(rs.choice([1, 1, 0])), "fused_sums": int(rs.choice([1, 0]))}
+                "pass_hints": int(rs.choice([1, 1, 0])), "fused_sums": int(rs.choice([1, 0])),
+                "xframe": int(rs.choice([1, 1, 0])), "multi_nt": int(rs.choice([-1, 1, 0])),
+                "init_prod_nt": int(rs.choice([-1, 1])), "pass_budget": int(rs.choice([0, 0, 30, 100]))}
         for kname, v in opts.items():
             eng.set_option(kname, v)
         rec, data = program.encode(ops)

@@ -435,7 +435,9 @@ def test_random_circuit_w20_against_c_oracle(be, fusion):
         elif name == "swap":
             ref.apply_mcx([q[0]], q[1]); ref.apply_mcx([q[1]], q[0]); ref.apply_mcx([q[0]], q[1])
         else: raise AssertionError(name)
-    for opts in ({}, {"zero_tracking": 1}, {"lane_targets": 0}, {"multi_r": 3}):
+    # multi_nt / init_prod_nt = 1: the non-temporal kernel forms, which a state this small would not select by itself
+    for opts in ({}, {"zero_tracking": 1}, {"lane_targets": 0}, {"multi_r": 3}, {"multi_nt": 1, "init_prod_nt": 1},
+                 {"multi_nt": 1, "zero_tracking": 1}, {"xframe": 0}):
         amp, meta = run_state(be, qc, fusion=fusion, engine_options=opts)
         assert np.abs(amp - ref.state).max() < 1e-12, (fusion, opts)
     be.run(qc, shots=0, engine_options={"zero_tracking": 0, "lane_targets": 1, "multi_r": 5})
@@ -551,8 +553,9 @@ def test_init_product_generator_against_numpy_engine():
             ref.exec(rec, data)
             want = ref.amplitudes()
             scale = np.abs(want).max()
-            for ip in (1, 0):
-                eng.set_option("init_prod", ip)
+            for ip in (1, 0, 2):
+                eng.set_option("init_prod", 1 if ip else 0)
+                eng.set_option("init_prod_nt", 1 if ip == 2 else 0)          # 2: the generator with non-temporal stores
                 eng.reset_stats()
                 eng.exec(rec, data)
                 kinds = {k: v["launches"] for k, v in eng.stats()["kinds"].items()}
@@ -561,6 +564,7 @@ def test_init_product_generator_against_numpy_engine():
                     assert kinds == {"init_prod": 1}
                 assert np.abs(eng.amplitudes() - want).max() < 1e-12 * max(1.0, scale), (case, ip)
         eng.set_option("init_prod", 1)
+        eng.set_option("init_prod_nt", -1)
         # a normalised product state: sample from the generator's tile sums
         ops = [ir.op_init((1 << W) - 1 - (1 << 3))]          # bit 7 populated by the folded-gate-like factor below
         for q in range(0, W - 1, 2):

@@ -142,6 +142,53 @@ def test_kq_dense(lib, n, k, mfma):
         assert np.abs(e.amplitudes() - ref).max() < 1e-12
 
 
+def test_nontemporal_kernel_forms(lib):
+    """every one-gate kernel in its non-temporal form (loads and stores that bypass the caches: what
+    states of >= 2^26 amplitudes select by themselves) against the numpy oracle at a size where the
+    plain form would be chosen: dense 1q on every target, MCX / controlled 2x2 with controls above
+    and inside a 128-byte line, diag, mux, dense 3..5-qubit gates on the matrix cores, norm"""
+    n = 14
+    rs = np.random.RandomState(77)
+    ref = rand_state(n, 41)
+    with lib.Engine(n) as e:
+        e.set_option("nontemporal", 1)
+        e.set_option("multi_nt", 1)
+        e.set_amplitudes(0, ref)
+        for t in range(n):
+            m = rand_u(1, 500 + t)
+            e.apply_1q(t, m)
+            sv.apply_1q(ref, t, m)
+        for trial in range(12):
+            nc = int(rs.randint(0, 4))
+            qs = [int(x) for x in rs.permutation(n)[: nc + 1]]
+            vals = [int(x) for x in rs.randint(0, 2, size=nc)]
+            e.apply_mcx(qs[:-1], qs[-1], vals)
+            sv.apply_mcx(ref, qs[:-1], qs[-1], vals)
+            m = rand_u(1, 600 + trial)
+            e.apply_1q(qs[-1], m, qs[:-1], vals)
+            sv.apply_1q(ref, qs[-1], m, qs[:-1], vals)
+            k = int(rs.randint(1, 5))
+            qs = [int(x) for x in rs.permutation(n)[:k + 1]]
+            tab = np.exp(1j * rs.uniform(-3, 3, size=2 ** (k + 1)))
+            e.apply_diag(qs, tab)
+            sv.apply_diag(ref, qs, tab)
+            mats = np.array([rand_u(1, 700 + 16 * trial + j) for j in range(2 ** k)])
+            e.apply_mux(qs[:-1], qs[-1], mats)
+            sv.apply_mux(ref, qs[:-1], qs[-1], mats)
+        for k in (3, 4, 5):
+            qs = [int(x) for x in rs.permutation(n)[:k]]
+            u = rand_u(k, 800 + k)
+            e.apply_kq(qs, u)
+            sv.apply_kq(ref, qs, u)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-12
+        assert abs(e.norm() - 1.0) < 1e-12
+        tab = rs.randn(8)
+        idx = np.arange(2 ** n)
+        j = ((idx >> 2) & 1) | (((idx >> 9) & 1) << 1) | (((idx >> 13) & 1) << 2)
+        got = e.expect_diag([2, 9, 13], tab)
+        assert abs(got[0] - (np.abs(ref) ** 2 * tab[j]).sum()) < 1e-12
+
+
 def test_init_uniform_and_zero(lib):
     n = 11
     with lib.Engine(n) as e:
