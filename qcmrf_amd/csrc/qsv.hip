@@ -192,6 +192,7 @@ struct qsv_handle {
   int opt_multi_nt = -1;              // k_multi with non-temporal loads + stores: -1 shards of >= 2^26 amplitudes, 0 never, 1 always
   int opt_init_prod_nt = -1;          // generator with non-temporal stores: -1 by shard size, 0 never, 1 always
   int opt_xframe = 1;                 // uncontrolled X gates inside a pass become an XOR on its store addresses
+  int opt_trace_passes = 0;           // 1: one stderr line per k_multi pass (R, mode, ops by update shape) -- a diagnostic
   int opt_pass_budget = 0;            // opt-in cap on the arithmetic of a general pass, percent of one read+write of the shard (0: none)
   uint64_t opt_xchunk = 1ull << 24;   // amplitudes per exchange chunk (256 MiB)
 };

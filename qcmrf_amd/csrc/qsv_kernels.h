@@ -608,17 +608,25 @@ __device__ __forceinline__ double wave_sum(double v);
 #define QSV_MULTI_MAXLIST 10
 
 struct MultiOp {
-  int type;                       // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase
-  int bit;                        // register bit of the target (types 0, 2)
-  int uniform;                    // 1: table index / condition independent of the register bits
-  int nlist;                      // entries of pos[] (types 0, 1)
+  int type;                       // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase | 4, 5: types 0, 2 on a lane bit
+  int bit;                        // register bit of the target (types 0, 2); lane bit (types 4, 5)
+  int uniform;                    // 1: table index (types 0, 1, 4) / control condition (2, 3, 5: rmask == 0) independent of the register bits
+  int nlist;                      // entries of pos[] (types 0, 1); types 2, 5: != 0 marks a plain X
   int tab;                        // table offset in LDS, in complex128 units
-  int regw[QSV_MULTI_MAXR];       // types 0,1: table-index weight of register bit c
-  int pos[QSV_MULTI_MAXLIST];     // types 0,1: address bit of list entry e; -1 if it is a register bit
+  int shape;                      // general passes: which of the eleven update shapes (GS_*) this op is
   unsigned int rmask, rval;       // types 2,3: condition on the register index
   unsigned long long tmask, tval; // types 2,3: condition on the lane/block part of the address
+  unsigned long long rfire;       // types 2,3,5: bit j set <=> (j & rmask) == rval, j = register index of an amplitude
   double m[8];                    // type 2: 2x2 row-major {re,im}; type 3: m[0..1] = phase
+  int regw[QSV_MULTI_MAXR];       // types 0,1: table-index weight of register bit c
+  int pos[QSV_MULTI_MAXLIST];     // types 0,1: address bit of list entry e; -1 if it is a register bit
 };
+// update shapes of a general pass.  Gates on a register bit: table with one matrix per thread / per
+// pair, controlled X, one controlled matrix; then the ops without a register target: diagonal table
+// with one entry per thread / per amplitude, controlled phase, lane-bit gate as a table (per thread /
+// per amplitude), controlled X on a lane bit, one controlled matrix on a lane bit
+enum { GS_TAB_T = 0, GS_TAB_P = 1, GS_X = 2, GS_MAT = 3, GS_DIAG_T = 4, GS_DIAG_A = 5, GS_PHASE = 6, GS_LTAB_T = 7,
+       GS_LTAB_A = 8, GS_LX = 9, GS_LMAT = 10 };
 struct RegPos { int pos[QSV_MULTI_MAXR]; };
 // Address bit carried by lane bits 3, 4, 5 of a wavefront.  Lane bits 0..2 are always address
 // bits 0..2 (8 lanes x 16 B = one 128-byte line per lane group); the upper three default to
@@ -648,79 +656,32 @@ __device__ __forceinline__ uint32_t multi_jt(const MultiOp& op, uint64_t base) {
   return jt;
 }
 
+// table-op passes (MODE 1, 2): a 2x2 gate on register bit B, one matrix per thread from the LDS table
 template <int R, int B, int MODE>
 __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
                                               const cplx* __restrict__ lt) {
+  static_assert(MODE >= 1, "general passes go through gen_op");
   constexpr int NP = (R > 0) ? (1 << (R - 1)) : 0;
-  if (MODE || op.type == 0) {
-    const uint32_t jt = multi_jt(op, base);
-    if (MODE || op.uniform) {
-      const cplx* mp = lt + op.tab + 4 * jt;
-      const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
-      if constexpr (MODE == 2) {
-        // every matrix of the pass has a real diagonal and an imaginary off-diagonal (RX-like: the
-        // real-part-extraction blocks, [[c, -is], [-is, c]]): half the flops of a general 2x2
-        const double c0 = m00.x, s0 = m01.y, s1 = m10.y, c1 = m11.x;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-          const cplx x = a[j0], y = a[j1];
-          a[j0] = make_double2(fma(c0, x.x, -s0 * y.y), fma(c0, x.y, s0 * y.x));
-          a[j1] = make_double2(fma(c1, y.x, -s1 * x.y), fma(c1, y.y, s1 * x.x));
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-          const cplx x = a[j0], y = a[j1];
-          a[j0] = cmad(m01, y, cmul(m00, x));
-          a[j1] = cmad(m11, y, cmul(m10, x));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-        int jr = 0;
-#pragma unroll
-        for (int c = 0; c < R; ++c) if ((j0 >> c) & 1) jr += op.regw[c];
-        const cplx* mp = lt + op.tab + 4 * (jt + jr);
-        const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
-        const cplx x = a[j0], y = a[j1];
-        a[j0] = cmad(m01, y, cmul(m00, x));
-        a[j1] = cmad(m11, y, cmul(m10, x));
-      }
-    }
-  } else if (op.nlist) {   // type 2, plain X (CX / CCX / MCX with +-flags): a masked register swap, no flops
-    const bool ct = (base & op.tmask) == op.tval;
-    // Masked register swap: eight selects per pair where the lane / block controls decide (an
-    // exec-masked v_swap_b32 version was tried: the compiler copies both operands first, 12
-    // instructions per pair).  The register part of the condition is wave-uniform (j0 is a
-    // compile-time constant): a REAL scalar branch skips the pairs it rules out -- a CCX with both
-    // controls on register bits touches a quarter of the tile; the empty asm keeps the compiler
-    // from turning the branch back into 2^R selects.
+  const cplx* mp = lt + op.tab + 4 * multi_jt(op, base);
+  const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+  if constexpr (MODE == 2) {
+    // every matrix of the pass has a real diagonal and an imaginary off-diagonal (RX-like: the
+    // real-part-extraction blocks, [[c, -is], [-is, c]]): half the flops of a general 2x2
+    const double c0 = m00.x, s0 = m01.y, s1 = m10.y, c1 = m11.x;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-      if (((unsigned)j0 & op.rmask) == op.rval) {
-        asm volatile("" ::);
-        const cplx x = a[j0], y = a[j1];
-        a[j0] = make_double2(ct ? y.x : x.x, ct ? y.y : x.y);
-        a[j1] = make_double2(ct ? x.x : y.x, ct ? x.y : y.y);
-      }
+      const cplx x = a[j0], y = a[j1];
+      a[j0] = make_double2(fma(c0, x.x, -s0 * y.y), fma(c0, x.y, s0 * y.x));
+      a[j1] = make_double2(fma(c1, y.x, -s1 * x.y), fma(c1, y.y, s1 * x.x));
     }
-  } else {   // type 2: one matrix where the controls match
-    const bool ct = (base & op.tmask) == op.tval;
-    const cplx m00 = make_double2(op.m[0], op.m[1]), m01 = make_double2(op.m[2], op.m[3]);
-    const cplx m10 = make_double2(op.m[4], op.m[5]), m11 = make_double2(op.m[6], op.m[7]);
+  } else {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int j0 = ((p >> B) << (B + 1)) | (p & ((1 << B) - 1)), j1 = j0 | (1 << B);
-      if ((((unsigned)j0 & op.rmask) == op.rval) && ct) {
-        const cplx x = a[j0], y = a[j1];
-        a[j0] = cmad(m01, y, cmul(m00, x));
-        a[j1] = cmad(m11, y, cmul(m10, x));
-      }
+      const cplx x = a[j0], y = a[j1];
+      a[j0] = cmad(m01, y, cmul(m00, x));
+      a[j1] = cmad(m11, y, cmul(m10, x));
     }
   }
 }
@@ -728,141 +689,272 @@ __device__ __forceinline__ void multi_2x2_bit(cplx (&a)[1 << R], const MultiOp& 
 // A 2x2 gate whose target is a LANE bit (address bit < 6): the partner amplitude of every register
 // sits in lane ^ (1 << bit) of the same wavefront, so the gate is a wave shuffle plus one complex
 // multiply-add per amplitude -- no extra HBM pass and no register bit spent.  With the six lane
-// bits a pass reaches R + 6 distinct targets.  type 4: table (mux) form, type 5: masked 2x2 / X.
+// bits a pass reaches R + 6 distinct targets.
 template <int R, int MODE>
-__device__ __forceinline__ void multi_lane_2x2(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
-                                               const cplx* __restrict__ lt) {
-  const int lm = 1 << op.bit;
-  const bool up = (threadIdx.x >> op.bit) & 1;            // this lane holds the |1> half of the pair
-  if (MODE || op.type == 4) {
-    const uint32_t jt = multi_jt(op, base);
-    if (MODE || op.uniform) {
-      const cplx* mp = lt + op.tab + 4 * jt;
-      const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
-      // chunks of 4 registers with a scheduling fence in between: left alone, hipcc hoists all
-      // 2^R x 2 shuffles ahead of the arithmetic and spills the tile (R = 5: +19 % HBM traffic)
-      if constexpr (MODE == 2) {
-        const double c = dg.x, sn = of.y;                 // real diagonal, imaginary off-diagonal
+__device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
+                                           const cplx* __restrict__ lt) {
+  static_assert(MODE >= 1, "general passes go through gen_op");
+  // ONE update path for every list op of a table-op pass: new = dg * own + of * partner, where a
+  // diagonal is the special case of = 0.  Branching between two whole-tile updates (diagonal vs
+  // lane gate) made hipcc keep both results alive: +70 VGPRs at R = 5, i.e. spills that showed up
+  // as +19 % HBM traffic in the PMC counters.
+  const uint32_t jt = multi_jt(op, base);
+  const bool lane_op = op.type == 4;
+  const int lm = lane_op ? (1 << op.bit) : 1;
+  const bool up = lane_op && ((threadIdx.x >> op.bit) & 1);   // this lane holds the |1> half of the pair
+  const cplx* mp = lt + op.tab + (lane_op ? 4 * jt : jt);
+  const cplx dg = lane_op ? (up ? mp[3] : mp[0]) : mp[0];
+  const cplx of = lane_op ? (up ? mp[2] : mp[1]) : make_double2(0.0, 0.0);
+  if constexpr (MODE == 2) {
+    const double c = dg.x, sn = of.y;                   // RX-like tables only (host guarantees: no diagonals)
 #pragma unroll
-        for (int j = 0; j < (1 << R); ++j) {
-          const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
-          a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
-          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < (1 << R); ++j) {
-          cplx o;
-          o.x = __shfl_xor(a[j].x, lm, 64);
-          o.y = __shfl_xor(a[j].y, lm, 64);
-          a[j] = cmad(of, o, cmul(dg, a[j]));
-          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < (1 << R); ++j) {
-        int jr = 0;
-#pragma unroll
-        for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += op.regw[c];
-        const cplx* mp = lt + op.tab + 4 * (jt + jr);
-        const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
-        cplx o;
-        o.x = __shfl_xor(a[j].x, lm, 64);
-        o.y = __shfl_xor(a[j].y, lm, 64);
-        a[j] = cmad(of, o, cmul(dg, a[j]));
-      }
+    for (int j = 0; j < (1 << R); ++j) {
+      const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
+      a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
     }
-  } else {   // type 5
-    const bool ct = (base & op.tmask) == op.tval;        // tmask never contains the target bit
-    const cplx dg = up ? make_double2(op.m[6], op.m[7]) : make_double2(op.m[0], op.m[1]);
-    const cplx of = up ? make_double2(op.m[4], op.m[5]) : make_double2(op.m[2], op.m[3]);
+  } else {
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
       cplx o;
       o.x = __shfl_xor(a[j].x, lm, 64);
       o.y = __shfl_xor(a[j].y, lm, 64);
-      const bool fire = (((unsigned)j & op.rmask) == op.rval) && ct;
-      const cplx own = a[j];
-      const cplx gated = cmad(of, o, cmul(dg, own));
-      // component-wise selects: a select between two cplx OBJECTS takes their addresses and
-      // sends the whole register tile to scratch
-      const double rx = op.nlist ? o.x : gated.x, ry = op.nlist ? o.y : gated.y;   // nlist != 0: plain X
-      a[j] = make_double2(fire ? rx : own.x, fire ? ry : own.y);
+      a[j] = cmad(of, o, cmul(dg, a[j]));
     }
   }
 }
 
-template <int R, int MODE>
-__device__ __forceinline__ void multi_diag(cplx (&a)[1 << R], const MultiOp& op, uint64_t base,
-                                           const cplx* __restrict__ lt) {
-  if constexpr (MODE >= 1) {
-    // ONE update path for every list op of a simple pass: new = dg * own + of * partner, where a
-    // diagonal is the special case of = 0.  Branching between two whole-tile updates (diagonal vs
-    // lane gate) made hipcc keep both results alive: +70 VGPRs at R = 5, i.e. spills that showed up
-    // as +19 % HBM traffic in the PMC counters.
-    const uint32_t jt = multi_jt(op, base);
-    const bool lane_op = op.type == 4;
-    const int lm = lane_op ? (1 << op.bit) : 1;
-    const bool up = lane_op && ((threadIdx.x >> op.bit) & 1);
-    const cplx* mp = lt + op.tab + (lane_op ? 4 * jt : jt);
-    const cplx dg = lane_op ? (up ? mp[3] : mp[0]) : mp[0];
-    const cplx of = lane_op ? (up ? mp[2] : mp[1]) : make_double2(0.0, 0.0);
-    if constexpr (MODE == 2) {
-      const double c = dg.x, sn = of.y;                   // RX-like tables only (host guarantees: no diagonals)
+// ---- GENERAL passes (MODE 0): every update in place ------------------------------------------
+// A general pass interprets a list of ops of eleven shapes.  Written as plain expressions, each
+// shape leaves its results in fresh registers and hipcc reconciles the shapes at every merge point
+// with a COPY OF THE WHOLE TILE (2^R x 2 v_mov_b64 per slot and per list op, taken or not: at
+// R = 4 six tile copies per round + one per list op -- more than half of the VALU work of the
+// reference's unfused stream, whose rounds hold ONE controlled X each).  Three rules keep the
+// tile where it is (found on reduced kernels; hipcc then emits no copy at all):
+//   1. an update is ONE inline-assembly statement, arithmetic included, whose outputs are TIED to
+//      the registers the amplitudes already live in (arithmetic left outside gets sunk below the
+//      statement and keeps the old value alive across it);
+//   2. no if / else with an update on both sides: the shapes are tested one after the other
+//      against a selector the compiler cannot see through (QSV_OPQ), so every update sits in a
+//      one-sided branch;
+//   3. controls on lane / block bits are a real exec-masked branch (a wave none of whose lanes
+//      match skips the op), register controls a scalar test per amplitude -- an op that does not
+//      fire costs its tests only.
+__device__ __forceinline__ void swap_inplace(cplx& x, cplx& y) {
+  double t;
+  asm("v_mov_b64 %4, %0\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %2, %4\n\t"
+      "v_mov_b64 %4, %1\n\tv_mov_b64 %1, %3\n\tv_mov_b64 %3, %4"
+      : "+v"(x.x), "+v"(x.y), "+v"(y.x), "+v"(y.y), "=&v"(t));
+}
+__device__ __forceinline__ void set_inplace(cplx& a, double vx, double vy) {    // a <- (vx, vy)
+  asm("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "+v"(a.x), "+v"(a.y) : "v"(vx), "v"(vy));
+}
+__device__ __forceinline__ void cmul_inplace(cplx& a, cplx d) {                 // a <- a * d
+  double t;
+  asm("v_mul_f64 %2, %1, %4\n\tv_mul_f64 %1, %1, %3\n\tv_fma_f64 %1, %0, %4, %1\n\tv_fma_f64 %0, %0, %3, -%2"
+      : "+v"(a.x), "+v"(a.y), "=&v"(t) : "v"(d.x), "v"(d.y));
+}
+__device__ __forceinline__ void cmul_inplace_s(cplx& a, cplx d) {               // same, d in SGPRs (one scalar operand per instruction)
+  double t;
+  asm("v_mul_f64 %2, %1, %4\n\tv_mul_f64 %1, %1, %3\n\tv_fma_f64 %1, %0, %4, %1\n\tv_fma_f64 %0, %0, %3, -%2"
+      : "+v"(a.x), "+v"(a.y), "=&v"(t) : "s"(d.x), "s"(d.y));
+}
+// (x, y) <- M (x, y): 16 multiply-adds + 3 moves.  MC = "v": matrix in VGPRs (a table entry per thread);
+// MC = "s": the op's own matrix straight from SGPRs (every instruction below names exactly ONE matrix
+// element, which is the one scalar operand a gfx9 VOP3 instruction may have)
+#define QSV_MAT2_INPLACE(NAME, MC)                                                                                      \
+__device__ __forceinline__ void NAME(cplx& x, cplx& y, cplx m00, cplx m01, cplx m10, cplx m11) {                       \
+  double t0, t1, t2;                                                                                                    \
+  asm("v_mul_f64 %4, %7, %0\n\tv_fma_f64 %4, -%8, %1, %4\n\tv_fma_f64 %4, %9, %2, %4\n\tv_fma_f64 %4, -%10, %3, %4\n\t"     \
+      "v_mul_f64 %5, %7, %1\n\tv_fma_f64 %5, %8, %0, %5\n\tv_fma_f64 %5, %9, %3, %5\n\tv_fma_f64 %5, %10, %2, %5\n\t"       \
+      "v_mul_f64 %6, %11, %0\n\tv_fma_f64 %6, -%12, %1, %6\n\tv_fma_f64 %6, %13, %2, %6\n\tv_fma_f64 %6, -%14, %3, %6\n\t"  \
+      "v_mul_f64 %3, %13, %3\n\tv_fma_f64 %3, %14, %2, %3\n\tv_fma_f64 %3, %11, %1, %3\n\tv_fma_f64 %3, %12, %0, %3\n\t"    \
+      "v_mov_b64 %2, %6\n\tv_mov_b64 %0, %4\n\tv_mov_b64 %1, %5"                                                      \
+      : "+v"(x.x), "+v"(x.y), "+v"(y.x), "+v"(y.y), "=&v"(t0), "=&v"(t1), "=&v"(t2)                                     \
+      : MC(m00.x), MC(m00.y), MC(m01.x), MC(m01.y), MC(m10.x), MC(m10.y), MC(m11.x), MC(m11.y));                        \
+}
+QSV_MAT2_INPLACE(mat2_inplace, "v")     // rows: t0 = x'.re, t1 = x'.im, t2 = y'.re, then y.im in place
+QSV_MAT2_INPLACE(mat2_inplace_s, "s")
+#undef QSV_MAT2_INPLACE
+// a <- dg * a + of * (ox, oy)   (the partner amplitude arrives by wave shuffle)
+__device__ __forceinline__ void lane_mix_inplace(cplx& a, double ox, double oy, cplx dg, cplx of) {
+  double t;
+  asm("v_mul_f64 %2, %1, %6\n\tv_mul_f64 %1, %1, %5\n\tv_fma_f64 %1, %0, %6, %1\n\tv_fma_f64 %1, %7, %4, %1\n\t"
+      "v_fma_f64 %1, %8, %3, %1\n\tv_fma_f64 %0, %0, %5, -%2\n\tv_fma_f64 %0, %7, %3, %0\n\tv_fma_f64 %0, -%8, %4, %0"
+      : "+v"(a.x), "+v"(a.y), "=&v"(t) : "v"(ox), "v"(oy), "v"(dg.x), "v"(dg.y), "v"(of.x), "v"(of.y));
+}
+__device__ __forceinline__ double shfl_at(double v, int byte_addr) {            // v of lane byte_addr / 4
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int R>
+__device__ __forceinline__ int multi_jr(const MultiOp& op, int j) {
+  int jr = 0;
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) {
-        const double ox = __shfl_xor(a[j].x, lm, 64), oy = __shfl_xor(a[j].y, lm, 64);
-        a[j] = make_double2(fma(c, a[j].x, -sn * oy), fma(c, a[j].y, sn * ox));
-      }
-    } else {
+  for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += op.regw[c];
+  return jr;
+}
+
+#define QSV_OPQ(x) ({ int _t = (x); asm volatile("" : "+s"(_t)); _t; })   // re-hide a scalar before every test (rule 2)
+// does amplitude j fire?  32-bit halves of the host-made mask: one s_bitcmp1_b32 + branch per test, firing path in line
+#define QSV_FIRES(flo, fhi, j) __builtin_expect(((((j) < 32 ? (flo) : (fhi)) >> ((j) & 31)) & 1u) != 0u, 1)
+#define QSV_PAIR(p, B) const int j0 = (((p) >> (B)) << ((B) + 1)) | ((p) & ((1 << (B)) - 1)), j1 = j0 | (1 << (B))
+
+// gate of a general pass on register bit B
+template <int R, int B>
+__device__ __forceinline__ void gen_gate(cplx (&a)[1 << R], const MultiOp& op, int shape, uint64_t base,
+                                         const cplx* __restrict__ lt) {
+  constexpr int NP = 1 << (R - 1);
+  if (QSV_OPQ(shape) < GS_X) {
+    if (QSV_OPQ(shape) == GS_TAB_T) {
+      const cplx* mp = lt + op.tab + 4 * multi_jt(op, base);
+      const cplx m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) {
-        cplx o;
-        o.x = __shfl_xor(a[j].x, lm, 64);
-        o.y = __shfl_xor(a[j].y, lm, 64);
-        a[j] = cmad(of, o, cmul(dg, a[j]));
+      for (int p = 0; p < NP; ++p) { QSV_PAIR(p, B); mat2_inplace(a[j0], a[j1], m00, m01, m10, m11); }
+    }
+    if (QSV_OPQ(shape) == GS_TAB_P) {
+      const uint32_t jt = multi_jt(op, base);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        QSV_PAIR(p, B);
+        const cplx* mp = lt + op.tab + 4 * (jt + multi_jr<R>(op, j0));
+        mat2_inplace(a[j0], a[j1], mp[0], mp[1], mp[2], mp[3]);
       }
     }
-    return;
   }
-  if (op.type >= 4) { multi_lane_2x2<R, MODE>(a, op, base, lt); return; }
-  if (MODE || op.type == 1) {
-    const uint32_t jt = multi_jt(op, base);
-    if (MODE || op.uniform) {
-      const cplx d = lt[op.tab + jt];
+  if (QSV_OPQ(shape) >= GS_X) {
+    if ((base & op.tmask) == op.tval) {                  // exec-masked: a wave without a matching lane skips the op
+      const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+      if (QSV_OPQ(shape) == GS_X) {
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) a[j] = cmul(a[j], d);
-    } else {
+        for (int p = 0; p < NP; ++p) { QSV_PAIR(p, B); if (QSV_FIRES(flo, fhi, j0)) swap_inplace(a[j0], a[j1]); }
+      }
+      if (QSV_OPQ(shape) == GS_MAT) {
+        const cplx m00 = make_double2(op.m[0], op.m[1]), m01 = make_double2(op.m[2], op.m[3]);
+        const cplx m10 = make_double2(op.m[4], op.m[5]), m11 = make_double2(op.m[6], op.m[7]);
 #pragma unroll
-      for (int j = 0; j < (1 << R); ++j) {
-        int jr = 0;
-#pragma unroll
-        for (int c = 0; c < R; ++c) if ((j >> c) & 1) jr += op.regw[c];
-        a[j] = cmul(a[j], lt[op.tab + jt + jr]);
+        for (int p = 0; p < NP; ++p) { QSV_PAIR(p, B); if (QSV_FIRES(flo, fhi, j0)) mat2_inplace_s(a[j0], a[j1], m00, m01, m10, m11); }
       }
     }
-  } else {   // type 3
-    const bool ct = (base & op.tmask) == op.tval;
-    // multiply by the phase where the lane / block controls match, by 1 elsewhere: no divergent
-    // branch; the register controls are a scalar (wave-uniform) test per amplitude
-    const cplx ph = make_double2(ct ? op.m[0] : 1.0, ct ? op.m[1] : 0.0);
-#pragma unroll
-    for (int j = 0; j < (1 << R); ++j)
-      if (((unsigned)j & op.rmask) == op.rval) {
-        asm volatile("" ::);                               // a real scalar branch: do not if-convert into 2^R multiplies + selects
-        a[j] = cmul(a[j], ph);
-      }
   }
 }
 
-// Schedule: the host lays the gates of a pass out in ROUNDS of 1 + R slots.  Slot 0 of a round is
-// a LIST of ops without a register target (diagonals, phases, lane-bit gates), slot 1 + b holds
-// (optionally) one 2x2-type gate on register bit b; a round runs its list, then bits 0..R-1.
-// The kernel body is therefore straight-line over b (each 2x2 path instantiated once, guarded by a
-// wave-uniform flag) inside one runtime loop over rounds -- no switch on the target bit, so every
-// amplitude is updated in place in its register (a switch made hipcc copy the whole tile per
-// case: 288 VGPRs at R = 5, spills at R = 6).
+// op of a general pass without a register target
+template <int R>
+__device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, int shape, uint64_t base,
+                                         const cplx* __restrict__ lt) {
+  if (QSV_OPQ(shape) < GS_LTAB_T) {
+    if (QSV_OPQ(shape) == GS_DIAG_T) {
+      const cplx d = lt[op.tab + multi_jt(op, base)];
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) cmul_inplace(a[j], d);
+    }
+    if (QSV_OPQ(shape) == GS_DIAG_A) {
+      const uint32_t jt = multi_jt(op, base);
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) cmul_inplace(a[j], lt[op.tab + jt + multi_jr<R>(op, j)]);
+    }
+    if (QSV_OPQ(shape) == GS_PHASE) {
+      if ((base & op.tmask) == op.tval) {
+        const cplx ph = make_double2(op.m[0], op.m[1]);
+        const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+#pragma unroll
+        for (int j = 0; j < (1 << R); ++j)
+          if (QSV_FIRES(flo, fhi, j)) cmul_inplace_s(a[j], ph);
+      }
+    }
+  }
+  if (QSV_OPQ(shape) >= GS_LTAB_T) {
+    // the partner amplitude sits in lane ^ (1 << bit): ds_bpermute with the byte address made ONCE per op
+    // (__shfl_xor recomputes its six-instruction address for every value it moves)
+    const int lane = threadIdx.x & 63;
+    const bool up = (lane >> op.bit) & 1;                // this lane holds the |1> half of the pair
+    const int partner = (lane ^ (1 << op.bit)) << 2;
+    if (QSV_OPQ(shape) == GS_LTAB_T) {
+      const cplx* mp = lt + op.tab + 4 * multi_jt(op, base);
+      const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) lane_mix_inplace(a[j], shfl_at(a[j].x, partner), shfl_at(a[j].y, partner), dg, of);
+    }
+    if (QSV_OPQ(shape) == GS_LTAB_A) {
+      const uint32_t jt = multi_jt(op, base);
+#pragma unroll
+      for (int j = 0; j < (1 << R); ++j) {
+        const cplx* mp = lt + op.tab + 4 * (jt + multi_jr<R>(op, j));
+        const cplx dg = up ? mp[3] : mp[0], of = up ? mp[2] : mp[1];
+        lane_mix_inplace(a[j], shfl_at(a[j].x, partner), shfl_at(a[j].y, partner), dg, of);
+      }
+    }
+    if (QSV_OPQ(shape) >= GS_LX) {
+      // tmask never contains the target bit, so a lane and its partner fire together.  No exec-masked
+      // branch here (the shuffles need every lane on): a lane whose controls do not match reads ITSELF
+      // (X) or mixes with the identity (matrix); a wave without any matching lane skips the op.
+      const bool ct = (base & op.tmask) == op.tval;
+      if (QSV_OPQ(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(ct) != 0)))) {
+        const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+        // no control on a register bit (the usual case): one block without tests, so the 2^R x 4
+        // shuffles are in flight together instead of one amplitude's at a time
+        const int all = __builtin_amdgcn_readfirstlane(op.uniform);
+        const int from = ct ? partner : (lane << 2);
+        const cplx dg = !ct ? make_double2(1.0, 0.0) : up ? make_double2(op.m[6], op.m[7]) : make_double2(op.m[0], op.m[1]);
+        const cplx of = !ct ? make_double2(0.0, 0.0) : up ? make_double2(op.m[4], op.m[5]) : make_double2(op.m[2], op.m[3]);
+        if (QSV_OPQ(all)) {
+          if (QSV_OPQ(shape) == GS_LX) {
+#pragma unroll
+            for (int j = 0; j < (1 << R); ++j) set_inplace(a[j], shfl_at(a[j].x, from), shfl_at(a[j].y, from));
+          }
+          if (QSV_OPQ(shape) == GS_LMAT) {
+#pragma unroll
+            for (int j = 0; j < (1 << R); ++j) lane_mix_inplace(a[j], shfl_at(a[j].x, partner), shfl_at(a[j].y, partner), dg, of);
+          }
+        }
+        if (!QSV_OPQ(all)) {
+          if (QSV_OPQ(shape) == GS_LX) {
+#pragma unroll
+            for (int j = 0; j < (1 << R); ++j)
+              if (QSV_FIRES(flo, fhi, j)) set_inplace(a[j], shfl_at(a[j].x, from), shfl_at(a[j].y, from));
+          }
+          if (QSV_OPQ(shape) == GS_LMAT) {
+#pragma unroll
+            for (int j = 0; j < (1 << R); ++j)
+              if (QSV_FIRES(flo, fhi, j)) lane_mix_inplace(a[j], shfl_at(a[j].x, partner), shfl_at(a[j].y, partner), dg, of);
+          }
+        }
+      }
+    }
+  }
+}
+
+// One op of a general pass.  The ops come as a flat list in program order: no rounds, no empty slots.
+template <int R>
+__device__ __forceinline__ void gen_op(cplx (&a)[1 << R], const MultiOp& op, uint64_t base, const cplx* __restrict__ lt) {
+  const int shape = __builtin_amdgcn_readfirstlane(op.shape);
+  if (QSV_OPQ(shape) < GS_DIAG_T) {
+    if constexpr (R > 0) {
+      const int b = __builtin_amdgcn_readfirstlane(op.bit);
+      if (QSV_OPQ(b) < 2) {
+        if (QSV_OPQ(b) == 0) gen_gate<R, 0>(a, op, shape, base, lt);
+        if constexpr (R > 1) if (QSV_OPQ(b) == 1) gen_gate<R, 1>(a, op, shape, base, lt);
+      }
+      if constexpr (R > 2) {
+        if (QSV_OPQ(b) >= 2) {
+          if (QSV_OPQ(b) == 2) gen_gate<R, 2>(a, op, shape, base, lt);
+          if constexpr (R > 3) if (QSV_OPQ(b) == 3) gen_gate<R, 3>(a, op, shape, base, lt);
+          if constexpr (R > 4) if (QSV_OPQ(b) == 4) gen_gate<R, 4>(a, op, shape, base, lt);
+          if constexpr (R > 5) if (QSV_OPQ(b) == 5) gen_gate<R, 5>(a, op, shape, base, lt);
+        }
+      }
+    }
+  }
+  if (QSV_OPQ(shape) >= GS_DIAG_T) gen_list<R>(a, op, shape, base, lt);
+}
+
+// Schedule of a TABLE-OP pass (MODE 1, 2): the host lays the gates out in ROUNDS of 1 + R slots.
+// Slot 0 of a round is a LIST of ops without a register target (diagonals, lane-bit gates), slot
+// 1 + b holds one 2x2 table gate on register bit b (an identity table where the circuit has none);
+// a round runs its list, then bits 0..R-1.  The kernel body is straight-line over b inside one
+// runtime loop over rounds -- no branch on the target bit or around an update, so plain expressions
+// already update every amplitude in place.
 struct MultiSlot { int first; int ndiag; int has; int pad; };   // list slot: ops[first .. first+ndiag); gate slot: ops[first] if has
 
 template <int R, int B, int MODE>
@@ -874,7 +966,7 @@ __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __r
     // SIMPLE passes apply a gate in EVERY slot (the host fills gaps with an identity table):
     // with no branch around the update, hipcc updates the tile in place instead of keeping an
     // old and a new copy alive across the merge.
-    if (MODE || sl.has) multi_2x2_bit<R, B, MODE>(a, ops[sl.first], base, lt);
+    multi_2x2_bit<R, B, MODE>(a, ops[sl.first], base, lt);
   }
 }
 
@@ -971,20 +1063,25 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
       else a[j] = NT ? ld_nt((pblk + off) + base_thr) : (pblk + off)[base_thr];
     }
   }
-  constexpr int NS = R + 1;
-  for (int r = 0; r < nrounds; ++r) {
-    const MultiSlot* rs = slots + r * NS;
-    {
-      const MultiSlot sl = rs[0];
-      const int nd = (r == 0 && list0_done) ? 0 : sl.ndiag;     // round 0's list already went into the scalar
-      for (int d = 0; d < nd; ++d) multi_diag<R, MODE>(a, ops[sl.first + d], base, lt);
+  if constexpr (MODE == 0) {
+    // general pass: `ops` is a flat list in program order, `nrounds` its length
+    for (int i = 0; i < nrounds; ++i) gen_op<R>(a, ops[i], base, lt);
+  } else {
+    constexpr int NS = R + 1;
+    for (int r = 0; r < nrounds; ++r) {
+      const MultiSlot* rs = slots + r * NS;
+      {
+        const MultiSlot sl = rs[0];
+        const int nd = (r == 0 && list0_done) ? 0 : sl.ndiag;     // round 0's list already went into the scalar
+        for (int d = 0; d < nd; ++d) multi_diag<R, MODE>(a, ops[sl.first + d], base, lt);
+      }
+      multi_slot<R, 0, MODE>(a, ops, rs, base, lt);
+      if constexpr (R > 1) multi_slot<R, 1, MODE>(a, ops, rs, base, lt);
+      if constexpr (R > 2) multi_slot<R, 2, MODE>(a, ops, rs, base, lt);
+      if constexpr (R > 3) multi_slot<R, 3, MODE>(a, ops, rs, base, lt);
+      if constexpr (R > 4) multi_slot<R, 4, MODE>(a, ops, rs, base, lt);
+      if constexpr (R > 5) multi_slot<R, 5, MODE>(a, ops, rs, base, lt);
     }
-    multi_slot<R, 0, MODE>(a, ops, rs, base, lt);
-    if constexpr (R > 1) multi_slot<R, 1, MODE>(a, ops, rs, base, lt);
-    if constexpr (R > 2) multi_slot<R, 2, MODE>(a, ops, rs, base, lt);
-    if constexpr (R > 3) multi_slot<R, 3, MODE>(a, ops, rs, base, lt);
-    if constexpr (R > 4) multi_slot<R, 4, MODE>(a, ops, rs, base, lt);
-    if constexpr (R > 5) multi_slot<R, 5, MODE>(a, ops, rs, base, lt);
   }
   // store side of the X frame: register, lane and block part of the mask
   uint64_t regbits = 0;

@@ -171,6 +171,27 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
     n_quiet_lane = min(LANE_BITS - len(lane_t), max(0, L - nd), len(quiet_u))
     # static lane targets take the lowest bits: bits 3..5 stay free to be lent out
     order = lane_t + quiet_u[:n_quiet_lane] + reg_t + quiet_u[n_quiet_lane:] + quiet_z + top_t   # physical 0, 1, 2, ...
+    # A gate-by-gate program (controlled X / phase / 2x2 ops, e.g. the reference's own stream at
+    # fusion 0) runs in GENERAL k_multi passes, where the economics differ (28 qubits, 60 ops a pass,
+    # profiles/r02w_pass_budget.log): a controlled X costs 31 us with its target on a register bit but
+    # 74 us on a lane bit (a wave shuffle of the whole tile), a 2x2 72 against 96 us, and an
+    # UNCONTROLLED X nothing anywhere (X frame).  So the lane bits go to the qubits that are the
+    # target of the fewest such ops, the most-targeted ones sit right above them.
+    masked = [op for op in ops if op.kind == "mcphase" or (op.kind in ("x", "u") and len(op.ctrls) > 0)]
+    free_x = sum(1 for op in ops if op.kind == "x" and len(op.ctrls) == 0)
+    if lane_targets and L >= 12 and 2 * len(masked) > len(ops) - free_x:
+        heat = {q: 0 for q in rest}
+        for op in ops:
+            if op.kind in ("u", "mux", "kq") or (op.kind == "x" and len(op.ctrls) > 0):
+                for q in op.dense_targets():
+                    if q in heat:
+                        heat[q] += 1
+        zeros = set(quiet_z)
+        cold = sorted((q for q in rest if q not in zeros), key=lambda q: (heat[q], 0 if (uniform >> q) & 1 else 1, q))
+        lanes = cold[:LANE_BITS]
+        above = sorted((q for q in rest if q not in zeros and q not in lanes), key=lambda q: (-heat[q], dense_first.get(q, never), q))
+        order = lanes + above + quiet_z
+        pass_heads = []
     lay = [0] * n_qubits
     for p, q in enumerate(order):
         lay[q] = p

@@ -15,6 +15,8 @@ eng.set_option("xframe", 0)
 tg = [8, 9, 10, 11]
 kinds = {
     "ccx_lane": lambda i: ir.op_x(tg[i % 4], [2, 3], [1, 0]),
+    "ccx_block": lambda i: ir.op_x(tg[i % 4], [20, 21], [1, 0]),
+    "ccx_reg": lambda i: ir.op_x(tg[i % 4], [tg[(i + 1) % 4], tg[(i + 2) % 4]], [1, 0]),
     "cp_regreg": lambda i: ir.op_mcphase([tg[(i + 1) % 4], tg[i % 4]], 0.3),
     "u_dense": lambda i: ir.op_u(tg[i % 4], ru()),
     "none": None,

@@ -35,6 +35,8 @@ for xf in (() if os.environ.get("QSV_STREAM_ONLY") else ((0,) if os.environ.get(
         run([ir.op_x(tg[i % RR], [2, 3], [1, 0]) for i in range(N)], "CCX (lane-bit controls)")
         run([ir.op_x(tg[i % RR], [tg[(i + 1) % RR], tg[(i + 2) % RR]], [1, 0]) for i in range(N)], "CCX (register controls)")
         run([ir.op_x(tg[i % RR], [20, 21], [1, 0]) for i in range(N)], "CCX (block-bit controls)")
+        run([ir.op_x(i % 3, [tg[i % RR], 20], [1, 0]) for i in range(N)], "CCX on a LANE target (register + block control)")
+        run([ir.op_u(i % 3, ru(), [20], [1]) for i in range(N)], "controlled 2x2 on a LANE target")
         run([ir.op_u(tg[i % RR], ru()) for i in range(N)], "dense 2x2 (type 2)")
         run([ir.op_u(tg[i % RR], ru(), [3], [1]) for i in range(N)], "controlled 2x2 (lane control)")
         run([ir.op_mcphase([2, tg[i % RR]], 0.3) for i in range(N)], "cp (lane + register)")
