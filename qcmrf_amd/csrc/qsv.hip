@@ -2,6 +2,10 @@
 // C ABI declared in include/qsv.h (which cites the reference call each entry point replaces).
 // gfx950 only; no CPU fallback of any kind: without a HIP device every entry point fails.
 #include "qsv_kernels.h"
+#include "qsv_kmulti_inst.h"
+QSV_KMULTI_FOR_GENERAL(QSV_KMULTI_DECLARE)
+QSV_KMULTI_FOR_MODE(QSV_KMULTI_DECLARE, 1)
+QSV_KMULTI_FOR_MODE(QSV_KMULTI_DECLARE, 2)
 #include "../../include/qsv.h"
 
 #include <rccl/rccl.h>
@@ -177,6 +181,7 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = -1;                    // one-gate sweeps non-temporal: -1 by shard size and bit positions (single_nt), 0 never, 1 always
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
+  int opt_general_r = 4;              // ... of a GENERAL pass (masked ops / register selects); also the tile it is padded to
   int opt_pair_variant = 0;           // experiments: see run_single
   int opt_lane_targets = 1;           // gates on address bits < 6 ride in k_multi passes as wave shuffles
   int opt_init_prod_bit0 = 0;         // first register bit of the generator: 0 by shard size (default), < 0 the top bits, 6 bits 6.. + lane map
