@@ -28,7 +28,7 @@ struct BitList {             // gather list: result bit b <- index bit pos[b]
 };
 struct Mat2 { double v[8]; };  // row-major {re,im}: m00 m01 m10 m11
 
-__device__ __forceinline__ uint64_t ins_bits(uint64_t x, const BitIns& b) {
+__host__ __device__ __forceinline__ uint64_t ins_bits(uint64_t x, const BitIns& b) {
   for (int j = 0; j < b.n; ++j) {
     const int p = b.pos[j];
     const uint64_t lo = x & ((1ull << p) - 1ull);

@@ -48,7 +48,7 @@ struct LanePos { int pos[3]; };
 
 // pos[0] < 0: plain mapping -- thread index bits fill the non-inserted address bits in order.
 // thread part / block part of a tile base address; thread index t = wave:2 | lane:6
-__device__ __forceinline__ uint32_t tile_base_thr(uint32_t t, const BitIns& ins, const LanePos& lp) {
+__host__ __device__ __forceinline__ uint32_t tile_base_thr(uint32_t t, const BitIns& ins, const LanePos& lp) {
   if (lp.pos[0] < 0) return (uint32_t)ins_bits((uint64_t)t, ins);
   const uint32_t u = ((t >> 6) << 3) | (t & 7u);
   return (uint32_t)ins_bits((uint64_t)u, ins) | (((t >> 3) & 1u) << lp.pos[0]) | (((t >> 4) & 1u) << lp.pos[1]) |
@@ -399,6 +399,10 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   // xmask (X frame): uncontrolled X gates of the pass are not executed as data movement at all --
   // the host conjugates every later op of the pass by them and the pass STORES each amplitude at
   // (its address XOR xmask): a wave store stays one contiguous run, the permutation is free.
+  // The host passes only bits for which that is race-free: register and LANE bits of a read+write
+  // pass (the wave that stores an address is the wave that loaded it, after its own loads), any bit
+  // of a write-only INIT pass.  An X on a bit that selects another wave / workgroup stays pending on
+  // the host (it conjugates the ops of the following passes too) until a pass can take it.
   // zreg (zero tracking): register bits whose qubit is still known to be |0> on entry -- every
   // amplitude with such a bit set is zero by construction and is not read (memory there may be
   // unwritten).  `ins` then also holds the known-zero NON-register bits, so only the populated

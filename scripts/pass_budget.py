@@ -15,7 +15,9 @@ eng.init_uniform((1 << W) - 1)
 eng.set_option("pass_budget", 0)
 import os
 RR = int(os.environ.get("QSV_R", "4"))
-eng.set_option("multi_r", RR)
+GR = int(os.environ.get("QSV_GR", "4"))                 # tile of the general pass (padded to it)
+eng.set_option("multi_r", max(RR, GR))
+eng.set_option("general_r", GR)
 tg = [8, 9, 10, 11][:RR]
 def run(ops, label):
     rec, data = program.encode(ops)

@@ -10,7 +10,7 @@ from oracle.sharded_numpy import NumpyEngine
 
 
 
-def run(n_cases=300, seed=7, verbose=True):
+def run(n_cases=300, seed=7, verbose=True, only=None, override=None):
     """returns the number of mismatching programs"""
     rs = np.random.RandomState(seed)
     bad = 0
@@ -76,7 +76,12 @@ def run(n_cases=300, seed=7, verbose=True):
                 "zero_tracking": int(rs.choice([0, 0, 0, 1])), "init_prod": int(rs.choice([1, 1, 0])),
                 "pass_hints": int(rs.choice([1, 1, 0])), "fused_sums": int(rs.choice([1, 0])),
                 "xframe": int(rs.choice([1, 1, 0])), "multi_nt": int(rs.choice([-1, 1, 0])),
-                "init_prod_nt": int(rs.choice([-1, 1])), "pass_budget": int(rs.choice([0, 0, 30, 100]))}
+                "init_prod_nt": int(rs.choice([-1, 1])), "pass_budget": int(rs.choice([0, 0, 30, 100])),
+                "general_r": int(rs.choice([4, 4, 5, 3, 2, 1]))}
+        if only is not None and (case != only if only >= 0 else case < -only):
+            continue                                       # replay mode (CASE, or -CASE: from that case on): the generator state advances, nothing runs
+        if override:
+            opts.update(override)
         for kname, v in opts.items():
             eng.set_option(kname, v)
         rec, data = program.encode(ops)
@@ -105,6 +110,8 @@ def run(n_cases=300, seed=7, verbose=True):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    override = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[4:])      # replay one case: N SEED CASE opt=value ...
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7, only=only, override=override)
     print("done: %d cases, %d mismatches" % (n, bad))
     sys.exit(1 if bad else 0)

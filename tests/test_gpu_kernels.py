@@ -421,3 +421,38 @@ def test_random_programs_differential(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(200, seed, verbose=False) == 0
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_x_frame_on_block_bits_of_a_state_wider_than_one_wave_of_workgroups(lib, P):
+    """An uncontrolled X rides in a pass as an XOR on the STORE addresses -- race-free only for bits inside
+    one wavefront's own tile (register + lane bits).  On a bit that selects another workgroup the X has to
+    stay pending across passes (or run as a swap): at 2^24 amplitudes the workgroups of a pass no longer
+    run all at once, so a store through such a bit would land in a tile nobody has read yet.  Program:
+    X gates on lane, wave, block and top bits interleaved with gates that force read+write passes
+    (general and table-op ones), one X left pending at the end; amplitudes against the numpy engine."""
+    from qcmrf_amd import ir, program
+    from oracle.sharded_numpy import NumpyEngine
+    W = 24
+    L = W - (P.bit_length() - 1)
+    rs = np.random.RandomState(5)
+    ops = [ir.op_init((1 << W) - 1)]
+    ops.append(ir.op_diag([0, 7, 13, L - 1], np.exp(1j * rs.randn(16))))           # make every amplitude distinct
+    ops.append(ir.op_diag([2, 6, 20, 9], np.exp(1j * rs.randn(16))))
+    for xq, (t, c) in zip([L - 1, 20, 7, 6, 2, 13, L - 1, 17], [(10, 3), (11, L - 1), (9, 20), (12, 7), (10, 13), (8, 2), (14, 6), (10, 17)]):
+        ops.append(ir.op_x(xq))
+        ops.append(ir.op_u(t, rand_u(1, 100 + t), [c], [1]))                      # general pass, control on the flipped bit
+        ops.append(ir.op_mux([xq], (t + 5) % 16 + 6 if (t + 5) % 16 + 6 != xq else 15, np.array([rand_u(1, 7), rand_u(1, 8)])))
+    ops.append(ir.op_x(19))                                                         # left pending at the end of the program
+    rec, data = program.encode(ops)
+    ref = NumpyEngine(W, P)
+    ref.exec(rec, data)
+    want = ref.amplitudes()
+    for opts in ({}, {"general_r": 3, "multi_r": 3}, {"xframe": 0}):
+        with lib.Engine(W, devices=(0,) * P) as eng:
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.exec(rec, data)
+            got = eng.amplitudes()
+            assert np.abs(got - want).max() < 1e-12, opts
+            assert abs(eng.norm() - 1.0) < 1e-10
