@@ -202,6 +202,11 @@ def test_full_size_w28_properties(be):
     assert meta["n_device_ops"] == 16
     _full_size_properties(be, C, engine_options={"zero_tracking": 1})
     _full_size_properties(be, C, fusion=1, engine_options={"zero_tracking": 0})
+    # the reference's own stream gate by gate: general k_multi passes (tile updated in place, X frame with
+    # bits pending across passes) at a size where the workgroups of a pass no longer run all at once
+    meta = _full_size_properties(be, C, fusion=0, profile=True)
+    assert meta["stats"]["kinds"]["multi"]["launches"] >= 5
+    _full_size_properties(be, C, fusion=0, engine_options={"xframe": 0})
 
 
 @pytest.mark.parametrize("P", [2, 4])
@@ -607,6 +612,7 @@ def test_full_size_w34_on_one_gpu(be):
     meta = _full_size_properties(be, C)
     assert meta["n_device_ops"] == 20
     _full_size_properties(be, C, fold_fresh=False)
+    _full_size_properties(be, C, fusion=0)                                     # 1154 gates one by one, 1.2 s
     be.run(__import__("qcmrf_amd").QCMRF([[0, 1]], [-0.1] * 4), shots=1)      # frees the 256 GiB
 
 
