@@ -73,6 +73,7 @@ main = run("default path", "")
 sweeps = run("full-width sweeps", "sweeps_")
 sweeps34 = run("full-width sweeps, 34 qubits", "sweeps34_")
 modes = run("general passes (MODE 1 / MODE 0), 28 qubits", "modes_")
+unfused = run("the reference's unfused stream (fusion 0), 28 qubits", "unfused_")
 tfile = os.path.join(PROF, "pmc_traffic.json")
 T = json.load(open(tfile)) if os.path.exists(tfile) else {}
 T["_method_" + tag] = ("scripts/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
@@ -95,8 +96,9 @@ put("k_multi", "hbm_bytes_per_launch_W34", sweeps34, "k_multi<5, false")
 put("k_multi_init", "hbm_bytes_per_launch_W34", sweeps34, "k_multi<5, true")
 put("k_multi_mode1", "hbm_bytes_per_launch_W28", modes, "k_multi<5, false, 1")
 put("k_multi_mode0", "hbm_bytes_per_launch_W28", modes, "k_multi<4, false, 0")
+put("k_multi_unfused_stream", "hbm_bytes_per_launch_W28", unfused, "k_multi<4, false, 0")
 json.dump(T, open(tfile, "w"), indent=1)
-for name, table in (("default", main), ("sweeps", sweeps), ("sweeps34", sweeps34), ("modes", modes)):
+for name, table in (("default", main), ("sweeps", sweeps), ("sweeps34", sweeps34), ("modes", modes), ("unfused", unfused)):
     for k, v in table.items():
         if "hbm_bytes" in v and v["hbm_bytes"] > 1e8:
             print("%-8s %-28s avg %.3f ms  HBM %.4f GB / launch" % (name, k, v.get("avg_ms_rocprof", float("nan")), v["hbm_bytes"] / 1e9))

@@ -1,7 +1,8 @@
 """GPU box: one line per k_multi pass of the reference's unfused stream (engine option trace_passes):
 register count, kernel mode, ops by update shape -- then the same run timed per kernel."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qcmrf_amd import QCMRF, workloads as wl
 from qcmrf_amd.backend import QsvBackend
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 28
