@@ -10,13 +10,14 @@ from oracle.sharded_numpy import NumpyEngine
 
 
 
-def run(n_cases=300, seed=7, verbose=True, only=None, override=None):
-    """returns the number of mismatching programs"""
+def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14, 15, 16, 17)):
+    """returns the number of mismatching programs.  widths: state sizes drawn from; at >= 21 qubits the
+    workgroups of a pass no longer run all at once (in-place permutations that cross workgroups show)"""
     rs = np.random.RandomState(seed)
     bad = 0
     engines = {}
     for case in range(n_cases):
-        W = int(rs.choice([14, 15, 16, 17]))
+        W = int(rs.choice(list(widths)))
         P = int(rs.choice([1, 1, 2, 4]))
         key = (W, P)
         if key not in engines:
@@ -110,7 +111,11 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "big" else None
+    if len(sys.argv) > 3 and sys.argv[3] == "big":          # N SEED big: wide states
+        bad = run(n, int(sys.argv[2]), widths=(21, 22, 23))
+        print("done: %d cases, %d mismatches" % (n, bad))
+        sys.exit(1 if bad else 0)
     override = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[4:])      # replay one case: N SEED CASE opt=value ...
     bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7, only=only, override=override)
     print("done: %d cases, %d mismatches" % (n, bad))

@@ -423,6 +423,18 @@ def test_random_programs_differential(seed):
     assert mod.run(200, seed, verbose=False) == 0
 
 
+def test_random_programs_differential_wide_states():
+    """the same at 21-23 qubits, where the workgroups of a pass run in several waves: an in-place
+    permutation that crossed workgroups (as the first X frame did on block bits) is invisible below"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("stress_random_programs", os.path.join(ROOT, "scripts", "stress_random_programs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(40, 3, verbose=False, widths=(21, 22, 23)) == 0
+
+
 @pytest.mark.parametrize("P", [1, 2])
 def test_x_frame_on_block_bits_of_a_state_wider_than_one_wave_of_workgroups(lib, P):
     """An uncontrolled X rides in a pass as an XOR on the STORE addresses -- race-free only for bits inside
