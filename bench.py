@@ -242,7 +242,7 @@ def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=(), *
     assert sum(counts.values()) == shots
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]
-    return {"elapsed": elapsed, "meta": meta, "agg": agg, "dom": dom,
+    return {"elapsed": elapsed, "meta": meta, "agg": agg, "dom": dom, "counts": counts,
             "breakdown_ms": {k: v / steps * 1e3 for k, v in t.items()},
             "kernels": {k: {"launches_per_step": a["launches"] / steps, "avg_ms": a["ms"] / a["launches"],
                             "GBps": a["bytes"] / a["ms"] / 1e6 if a["ms"] > 0 else None} for k, a in agg.items()},
@@ -250,6 +250,40 @@ def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=(), *
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBPS,
                          "traffic": None, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                          "avg_launch_ms": d["ms"] / d["launches"], "rank": 0}}
+
+
+def validate_last_step(backend, comm, qc, cliques, theta, counts, shots):
+    """Sanity of the result the timed steps produced -- outside the timed region, product code only
+    (qcmrf_amd.mrf is the host restatement of eval.py's Gibbs arithmetic, not the oracle): the state's norm
+    summed over every rank's shard, the rate at which all real-part-extraction ancillas read 0 against
+    Z / 2^n, and -- when enough shots pass the post-selection -- the conditional distribution of the
+    variables against the Gibbs pmf (fidelity as run_experiment.py reports it)."""
+    from qcmrf_amd import extract_probs, fidelity, mrf
+    n = qc.num_vertices
+    W = qc.num_qubits
+    norm = float(np.sum(comm.allgather_f64(backend.last_engine.norm())))          # each rank holds its own shard's share
+    P, rate = extract_probs(counts, n, W - n)
+    p, lnZ = mrf.gibbs_pmf(cliques, theta)
+    want = mrf.success_probability(cliques, theta)
+    sigma = (want * (1.0 - want) / shots) ** 0.5
+    # the conditional pmf is only worth comparing when enough shots passed the post-selection (an exact sampler scores
+    # about 1 - (support - 1) / (4 N) against p with N of them); at the bench's 4096 shots it rarely is
+    n_ok = int(round(rate * shots))
+    support = int((p > 1e-12).sum())
+    fid = float(fidelity(P, p)) if n_ok >= 4 * support else None
+    # exact, whatever the shot count: one read pass over the resident state on every rank (qsv_expect_diag) gives
+    # P(all ancillas 0) and <H> in the post-selected state; both against the Gibbs arithmetic to 1e-9
+    hdiag = qc.hamiltonian_diagonal()                       # index bit q <-> qubit q, variable v on qubit n-1-v: gibbs_pmf's order
+    s0, s1 = backend.expectation_diagonal(hdiag, list(range(n)), {q: 0 for q in range(n, W)})
+    h_dev, h_want = s0 / s1, float(np.dot(p, hdiag))
+    ok = (abs(norm - 1.0) < 1e-9 and abs(s1 - want) < 1e-9 and abs(h_dev - h_want) < 1e-9 * max(1.0, abs(h_want))
+          and abs(rate - want) < 5.0 * sigma + 1e-3 and (fid is None or fid > 0.9))
+    return {"ok": bool(ok), "norm_over_all_shards": norm, "p_all_ancillas_0_on_device": s1, "expected_Z_over_2n": want,
+            "H_post_selected_on_device": h_dev, "H_gibbs": h_want,
+            "sampled_success_rate": float(rate), "binomial_sigma": sigma, "post_selected_shots": n_ok, "fidelity_to_gibbs_pmf": fid,
+            "note": "last timed step, computed after the timed region: norm and the two device expectations are exact checks "
+                    "(1e-9) of the state in HBM across all ranks; the sampled rate is within 5 sigma; fidelity only when "
+                    ">= 4 x support shots passed the post-selection"}
 
 
 PMC_FILE = "profiles/pmc_traffic.json"
@@ -403,6 +437,7 @@ def main():
 
     main_leg = timed_leg(backend, comm, qc, args.shots, args.steps, args.warmup, options=args.option)
     elapsed, meta, agg = main_leg["elapsed"], main_leg["meta"], main_leg["agg"]
+    validation = validate_last_step(backend, comm, qc, cliques, theta, main_leg["counts"], args.shots)
 
     # untimed-for-`value` extra legs (every rank takes part; reported under "variants")
     variants = {}
@@ -552,6 +587,7 @@ def main():
             "breakdown_ms": main_leg["breakdown_ms"],
             "kernels": main_leg["kernels"],
             "roofline": roof,
+            "validation": validation,
         }
         line["variants"] = variants
         # the same circuit with every fused gate swept over the full vector (fold_fresh off): the
