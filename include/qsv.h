@@ -250,7 +250,20 @@ int qsv_get_stats(qsv_handle* h, qsv_stats* out);
 int qsv_timer_begin(qsv_handle* h);
 int qsv_timer_end(qsv_handle* h, double* ms);
 
-/* tuning knobs: "grid_cap", "unroll", "lowt_shuffle", "nontemporal" ... (-1 if unknown) */
+/* Tuning knobs (defaults in brackets; none of them changes a result, only how it is computed).  Unknown
+ * name or value out of range: QSV_E_BADARG.
+ *   passes      multi_r [5]        register targets of a k_multi pass at most (0: one kernel per gate)
+ *               general_r [4]      ... of a GENERAL pass (masked X / 2x2 / phase, register selects); its tile width
+ *               pass_max_ops [64]  ops per pass at most        pass_budget [0]   arithmetic cap of a general pass, % of one sweep
+ *               lane_targets [1]   targets < 6 ride on lane bits (wave shuffles)   dyn_lanes [3]  lane bits 3..5 lent per pass
+ *               lane_map [1]       lane bit 5 on address bit 11 when the tile is bits 6..10     pass_hints [1]  honour QSV_OPF_NEW_PASS
+ *               xframe [1]         uncontrolled X = XOR on store addresses / pending across passes (never a data move)
+ *               single_shortcut [1] a one-op pass runs as its dedicated kernel     trace_passes [0]  one stderr line per pass
+ *   generator   init_prod [1]      init x diagonal factors in one write-only pass   init_prod_r [0 = by shard size], init_prod_bit0 [0 = by size]
+ *   memory      nontemporal [-1], multi_nt [-1], init_prod_nt [-1]   non-temporal loads/stores: -1 by shard size, 0 never, 1 always
+ *   measurement cache_sums [1], fused_sums [1]   keep / produce per-tile |amp|^2 sums in the last pass of a program
+ *   kernels     unroll [4], lowt_shuffle [1], pair_variant [0], kq_mfma [1], blocks_per_cu [65536]
+ *   other       zero_tracking [0]  skip amplitudes known to be zero (opt-in)       exchange_chunk_log2 [24]  amplitudes per exchange chunk */
 int qsv_set_option(qsv_handle* h, const char* name, int value);
 
 const char* qsv_last_error(void);
