@@ -409,14 +409,19 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   // subspace is enumerated at all.
   extern __shared__ double4 lds_raw[];
   cplx* lt = reinterpret_cast<cplx*>(lds_raw);
-  for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = tables[i];
-  __syncthreads();
-  const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
-  if (gb + threadIdx.x >= nthreads) return;
   // address = (uniform 64-bit pointer: shard + block part + register offset) + 32-bit lane part
   const uint64_t base_blk = tile_base_blk(blockIdx.x, ins, lp);      // wave-uniform
   const uint32_t base_thr = tile_base_thr(threadIdx.x, ins, lp);
   const uint64_t base = base_blk | base_thr;
+  // The gate tables go to LDS -- unless this is an init pass and the whole workgroup starts from zeros (see
+  // `live` below: all but one workgroup in 2^(ancillas outside the tile) of a QCMRF circuit): it then runs
+  // no op, needs no table, and is a plain fill.
+  const bool need_tables = !INIT || __syncthreads_or((int)((base & nonmask) == 0));
+  if (need_tables)
+    for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lt[i] = tables[i];
+  __syncthreads();
+  const uint64_t gb = (uint64_t)blockIdx.x * QSV_TPB;
+  if (gb + threadIdx.x >= nthreads) return;
   cplx* __restrict__ pblk = amp + base_blk;
   // register-bit offsets once, in SGPRs (otherwise every one of the 2^R loads re-reads its
   // positions from the kernel arguments and waits for them)
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   }
   cplx a[1 << R];
   int list0_done = 0;
+  bool live = true;               // INIT: does this wavefront hold a nonzero amplitude at all?
   if (INIT) {
     // Every register bit of a fused QCMRF pass is a fresh |0> target: the tile starts as ONE
     // nonzero amplitude per lane (j = 0).  The first round's list ops (lane gates, diagonals) map
@@ -460,6 +466,11 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
       for (int c = 0; c < R; ++c) if ((j >> c) & 1) off |= ob[c];
       a[j] = ((off & nonmask) == 0) ? f : make_double2(0.0, 0.0);
     }
+    // Most wavefronts of an init pass start from NOTHING: an amplitude is nonzero only where every qubit
+    // outside the uniform-superposition mask reads 0 (all ancillas: one address in 2^m), and gates map
+    // zero tiles to zero tiles.  Such a wave skips the ops and just writes its zeros, so a write-only pass
+    // has (almost) no arithmetic left to hide.
+    live = __builtin_amdgcn_ballot_w64(f.x != 0.0 || f.y != 0.0) != 0;
   } else if (zreg == 0) {                       // the common case: no branch between the loads
 #pragma unroll
     for (int j = 0; j < (1 << R); ++j) {
@@ -480,10 +491,12 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
   }
   if constexpr (MODE == 0) {
     // general pass: `ops` is a flat list in program order, `nrounds` its length
-    for (int i = 0; i < nrounds; ++i) gen_op<R>(a, ops[i], base, lt);
+    const int nops = (!INIT || live) ? nrounds : 0;
+    for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[i], base, lt);
   } else {
     constexpr int NS = R + 1;
-    for (int r = 0; r < nrounds; ++r) {
+    const int nr = (!INIT || live) ? nrounds : 0;
+    for (int r = 0; r < nr; ++r) {
       const MultiSlot* rs = slots + r * NS;
       {
         const MultiSlot sl = rs[0];
