@@ -254,6 +254,7 @@ int qsv_timer_end(qsv_handle* h, double* ms);
  * name or value out of range: QSV_E_BADARG.
  *   passes      multi_r [5]        register targets of a k_multi pass at most (0: one kernel per gate)
  *               general_r [4]      ... of a GENERAL pass (masked X / 2x2 / phase, register selects); its tile width
+ *               general_light_r [5] tile width a general pass with little arithmetic is padded to
  *               pass_max_ops [64]  ops per pass at most        pass_budget [0]   arithmetic cap of a general pass, % of one sweep
  *               lane_targets [1]   targets < 6 ride on lane bits (wave shuffles)   dyn_lanes [3]  lane bits 3..5 lent per pass
  *               lane_map [1]       lane bit 5 on address bit 11 when the tile is bits 6..10     pass_hints [1]  honour QSV_OPF_NEW_PASS

@@ -18,6 +18,7 @@ RR = int(os.environ.get("QSV_R", "4"))
 GR = int(os.environ.get("QSV_GR", "4"))                 # tile of the general pass (padded to it)
 eng.set_option("multi_r", max(RR, GR))
 eng.set_option("general_r", GR)
+if os.environ.get("QSV_GLR"): eng.set_option("general_light_r", int(os.environ["QSV_GLR"]))
 tg = [8, 9, 10, 11][:RR]
 def run(ops, label):
     rec, data = program.encode(ops)
