@@ -257,13 +257,14 @@ int qsv_timer_end(qsv_handle* h, double* ms);
  *               general_light_r [5] tile width a general pass with little arithmetic is padded to
  *               pass_max_ops [64]  ops per pass at most        pass_budget [0]   arithmetic cap of a general pass, % of one sweep
  *               lane_targets [1]   targets < 6 ride on lane bits (wave shuffles)   dyn_lanes [3]  lane bits 3..5 lent per pass
- *               lane_map [1]       lane bit 5 on address bit 11 when the tile is bits 6..10     pass_hints [1]  honour QSV_OPF_NEW_PASS
+ *               lane_map [1]       lane bit 5 on address bit 11 when the tile allows (2: only a tile on bits 6..10; 0: never)    pass_hints [1]  honour QSV_OPF_NEW_PASS
  *               xframe [1]         uncontrolled X = XOR on store addresses / pending across passes (never a data move)
  *               single_shortcut [1] a one-op pass runs as its dedicated kernel     trace_passes [0]  one stderr line per pass
  *   generator   init_prod [1]      init x diagonal factors in one write-only pass   init_prod_r [0 = by shard size], init_prod_bit0 [0 = by size]
  *   memory      nontemporal [-1], multi_nt [-1], init_prod_nt [-1]   non-temporal loads/stores: -1 by shard size, 0 never, 1 always
  *   measurement cache_sums [1], fused_sums [1]   keep / produce per-tile |amp|^2 sums in the last pass of a program
  *   kernels     unroll [4], lowt_shuffle [1], pair_variant [0], kq_mfma [1], blocks_per_cu [65536]
+ *               swizzle [1]        one-gate kernels: lane bit 5 of a wave access carries address bit 11 (two 512-byte runs 32 KiB apart)
  *   other       zero_tracking [0]  skip amplitudes known to be zero (opt-in)       exchange_chunk_log2 [24]  amplitudes per exchange chunk */
 int qsv_set_option(qsv_handle* h, const char* name, int value);
 

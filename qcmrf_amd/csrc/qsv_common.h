@@ -36,6 +36,16 @@ __host__ __device__ __forceinline__ uint64_t ins_bits(uint64_t x, const BitIns& 
   }
   return x;
 }
+// Which amplitudes one wave instruction touches is a free choice in a sweep kernel (any bijection between
+// work items and amplitudes will do), and it matters: a wavefront access made of two 512-byte runs
+// 32 KiB apart -- lane bit 5 carrying address bit 11 instead of bit 5 -- streams 8-13 % faster on MI355X
+// than one contiguous 1 KiB (profiles/r02_lane_map_high_target.log; no other bit does it).  swz_5_11
+// exchanges the two bits of an amplitude index; a kernel applies it when neither is a bit the gate
+// singles out (target, control, select), so a pair stays a pair.
+__host__ __device__ __forceinline__ uint64_t swz_5_11(uint64_t i) {
+  const uint64_t d = ((i >> 5) ^ (i >> 11)) & 1ull;
+  return i ^ (d << 5) ^ (d << 11);
+}
 __device__ __forceinline__ uint32_t gather_bits(uint64_t x, const BitList& b) {
   uint32_t j = 0;
   for (int k = 0; k < b.n; ++k) j |= (uint32_t)((x >> b.pos[k]) & 1ull) << k;

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_init(cplx* __restrict__ amp, uint64
 template <int KIND, int U, bool GUARD, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64_t npairs,
                                                   BitIns ins, uint64_t fixed, uint64_t tbit,
-                                                  Mat2 m) {
+                                                  Mat2 m, int swz) {
   const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
   const cplx m00 = make_double2(m.v[0], m.v[1]), m01 = make_double2(m.v[2], m.v[3]);
   const cplx m10 = make_double2(m.v[4], m.v[5]), m11 = make_double2(m.v[6], m.v[7]);
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
       if (!GUARD || p < npairs) {
         i0[u] = ins_bits(p, ins) | fixed;
+        if (swz) i0[u] = swz_5_11(i0[u]);
         a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
         a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
       }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64
 // ---------------------------------------------------------------------------------------
 template <int U, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_lowt(cplx* __restrict__ amp, uint64_t n, int t,
-                                                  Mat2 m) {
+                                                  Mat2 m, int swz) {
   const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
   const int b = (threadIdx.x >> t) & 1;
   // row b of the matrix: out = diag * own + off * partner
@@ -75,17 +76,21 @@ __global__ __launch_bounds__(QSV_TPB) void k_lowt(cplx* __restrict__ amp, uint64
   for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n;
        base += stride) {
     cplx a[U];
+    uint64_t ix[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      a[u] = NT ? ld_nt(amp + base + (uint64_t)u * QSV_TPB) : ld(amp + base + (uint64_t)u * QSV_TPB);
+    for (int u = 0; u < U; ++u) {
+      ix[u] = base + (uint64_t)u * QSV_TPB;
+      if (swz) ix[u] = swz_5_11(ix[u]);          // t < 5: lane bits 0..4 still are address bits 0..4
+      a[u] = NT ? ld_nt(amp + ix[u]) : ld(amp + ix[u]);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       cplx o;
       o.x = __shfl_xor(a[u].x, lm, 64);
       o.y = __shfl_xor(a[u].y, lm, 64);
       const cplx r = cmad(of, o, cmul(dg, a[u]));
-      if (NT) st_nt(amp + base + (uint64_t)u * QSV_TPB, r);
-      else    st(amp + base + (uint64_t)u * QSV_TPB, r);
+      if (NT) st_nt(amp + ix[u], r);
+      else    st(amp + ix[u], r);
     }
   }
 }
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_lowt(cplx* __restrict__ amp, uint64
 template <int U, bool GUARD, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_mux(cplx* __restrict__ amp, uint64_t npairs,
                                                  int t, BitList ctl,
-                                                 const double* __restrict__ mats, int nmat) {
+                                                 const double* __restrict__ mats, int nmat, int swz) {
   extern __shared__ double4 lds_mats[];   // nmat x 2 double4 = {m00,m01},{m10,m11}
   {
     const double4* src = reinterpret_cast<const double4*>(mats);
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_mux(cplx* __restrict__ amp, uint64_
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
       if (!GUARD || p < npairs) {
         i0[u] = ((p >> t) << (t + 1)) | (p & lomask);
+        if (swz) i0[u] = swz_5_11(i0[u]);
         a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
         a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
       }
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_mux(cplx* __restrict__ amp, uint64_
 template <int U, bool GUARD, bool LDS, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_diag(cplx* __restrict__ amp, uint64_t n,
                                                   BitList q, const cplx* __restrict__ table,
-                                                  int ntab) {
+                                                  int ntab, int swz) {
   extern __shared__ double4 lds_raw[];
   cplx* lt = reinterpret_cast<cplx*>(lds_raw);
   if (LDS) {
@@ -155,14 +161,16 @@ __global__ __launch_bounds__(QSV_TPB) void k_diag(cplx* __restrict__ amp, uint64
   for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n;
        base += stride) {
     cplx a[U];
+    uint64_t ix[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t i = base + (uint64_t)u * QSV_TPB;
-      if (!GUARD || i < n) a[u] = NT ? ld_nt(amp + i) : ld(amp + i);
+      ix[u] = base + (uint64_t)u * QSV_TPB;
+      if (swz) ix[u] = swz_5_11(ix[u]);            // every amplitude is on its own: any bijection will do
+      if (!GUARD || ix[u] < n) a[u] = NT ? ld_nt(amp + ix[u]) : ld(amp + ix[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t i = base + (uint64_t)u * QSV_TPB;
+      const uint64_t i = ix[u];
       if (!GUARD || i < n) {
         const uint32_t j = gather_bits(i, q);
         const cplx d = LDS ? lt[j] : table[j];
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_diag(cplx* __restrict__ amp, uint64
 // phase on the control-satisfied subspace only: i = ins(p) | fixed, p < 2^(L - n_ctrl)
 template <int U, bool GUARD>
 __global__ __launch_bounds__(QSV_TPB) void k_mcphase(cplx* __restrict__ amp, uint64_t nsub,
-                                                     BitIns ins, uint64_t fixed, cplx ph) {
+                                                     BitIns ins, uint64_t fixed, cplx ph, int swz) {
   const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
   for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < nsub;
        base += stride) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_mcphase(cplx* __restrict__ amp, uin
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
-      if (!GUARD || p < nsub) { idx[u] = ins_bits(p, ins) | fixed; a[u] = amp[idx[u]]; }
+      if (!GUARD || p < nsub) { idx[u] = ins_bits(p, ins) | fixed; if (swz) idx[u] = swz_5_11(idx[u]); a[u] = amp[idx[u]]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -326,14 +334,15 @@ __global__ __launch_bounds__(QSV_TPB) void k_unpack_block(cplx* __restrict__ amp
 // sums[b] = sum |amp|^2 over block b (fixed-order tree: deterministic)
 template <bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_blocksum(const cplx* __restrict__ amp, uint64_t n,
-                                                      double* __restrict__ sums, uint64_t nblocks) {
+                                                      double* __restrict__ sums, uint64_t nblocks, int swz) {
   __shared__ double part[QSV_TPB / 64];
   for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const uint64_t lo = b * QSV_SBLOCK;
     double s = 0.0;
 #pragma unroll 4
     for (int k = 0; k < QSV_SBLOCK / QSV_TPB; ++k) {
-      const uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
+      uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
+      if (swz) i = swz_5_11(i);                    // stays inside the block (both bits < log2 QSV_SBLOCK)
       if (i < n) { const cplx a = NT ? ld_nt(amp + i) : amp[i]; s = fma(a.x, a.x, fma(a.y, a.y, s)); }
     }
     s = wave_sum(s);
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
 template <bool LDS, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict__ amp, uint64_t n, uint64_t hi, BitList q,
                                                          uint64_t fmask, uint64_t fval, const double* __restrict__ table,
-                                                         int ntab, double* __restrict__ partial) {
+                                                         int ntab, double* __restrict__ partial, int swz) {
   extern __shared__ double lds_tab[];
   if (LDS) {
     for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lds_tab[i] = table[i];
@@ -505,14 +514,16 @@ __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict_
   double s0 = 0.0, s1 = 0.0;
   for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n; base += stride) {
     cplx a[U];
+    uint64_t ix[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t i = base + (uint64_t)u * QSV_TPB;
-      a[u] = i < n ? (NT ? ld_nt(amp + i) : amp[i]) : make_double2(0.0, 0.0);
+      ix[u] = base + (uint64_t)u * QSV_TPB;
+      if (swz) ix[u] = swz_5_11(ix[u]);
+      a[u] = ix[u] < n ? (NT ? ld_nt(amp + ix[u]) : amp[ix[u]]) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t g = hi | (base + (uint64_t)u * QSV_TPB);
+      const uint64_t g = hi | ix[u];
       const double p = ((g & fmask) == fval) ? fma(a[u].x, a[u].x, a[u].y * a[u].y) : 0.0;
       const uint32_t j = gather_bits(g, q);
       const double t = LDS ? lds_tab[j] : table[j];
