@@ -189,6 +189,42 @@ def test_nontemporal_kernel_forms(lib):
         assert abs(got[0] - (np.abs(ref) ** 2 * tab[j]).sum()) < 1e-12
 
 
+@pytest.mark.parametrize("swizzle", [1, 0])
+def test_index_swizzle_of_the_one_gate_kernels(lib, swizzle):
+    """The one-gate sweep kernels index their amplitudes with bits 5 and 11 exchanged (a wave access = two
+    512-byte runs 32 KiB apart) unless one of the two is a bit the gate singles out.  Gates
+    whose target / controls / selects sit on bits 5, 11 or next to them, both ways, against numpy."""
+    n = 16
+    rs = np.random.RandomState(5 + swizzle)
+    ref = rand_state(n, 43)
+    with lib.Engine(n) as e:
+        e.set_option("swizzle", swizzle)
+        e.set_amplitudes(0, ref)
+        for t in (0, 4, 5, 6, 10, 11, 12, 15):
+            m = rand_u(1, 900 + t)
+            e.apply_1q(t, m)
+            sv.apply_1q(ref, t, m)
+        for ctrls, t in (([5], 11), ([11], 5), ([5, 11], 3), ([3], 12), ([12, 4], 5), ([6], 11), ([10, 2], 14), ([], 5), ([], 11)):
+            vals = [int(x) for x in rs.randint(0, 2, size=len(ctrls))]
+            e.apply_mcx(ctrls, t, vals)
+            sv.apply_mcx(ref, ctrls, t, vals)
+            m = rand_u(1, 950 + t + len(ctrls))
+            e.apply_1q(t, m, ctrls, vals)
+            sv.apply_1q(ref, t, m, ctrls, vals)
+            qs = ctrls + [t]
+            ang = float(rs.uniform(-3, 3))
+            e.apply_mcphase(qs, ang, [1] * len(qs))
+            sv.apply_mcphase(ref, qs, ang, [1] * len(qs))
+            tab = np.exp(1j * rs.uniform(-3, 3, size=2 ** len(qs)))
+            e.apply_diag(qs, tab)
+            sv.apply_diag(ref, qs, tab)
+            mats = np.array([rand_u(1, 1000 + 8 * t + j) for j in range(2 ** len(ctrls))])
+            e.apply_mux(ctrls, t, mats)
+            sv.apply_mux(ref, ctrls, t, mats)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-12
+        assert abs(e.norm() - 1.0) < 1e-12
+
+
 def test_init_uniform_and_zero(lib):
     n = 11
     with lib.Engine(n) as e:
