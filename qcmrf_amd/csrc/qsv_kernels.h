@@ -342,7 +342,8 @@ __global__ __launch_bounds__(QSV_TPB) void k_blocksum(const cplx* __restrict__ a
 #pragma unroll 4
     for (int k = 0; k < QSV_SBLOCK / QSV_TPB; ++k) {
       uint64_t i = lo + (uint64_t)k * QSV_TPB + threadIdx.x;
-      if (swz) i = swz_5_11(i);                    // stays inside the block (both bits < log2 QSV_SBLOCK)
+      if (swz & 2) i = lo + (uint64_t)(threadIdx.x >> 6) * (QSV_SBLOCK / (QSV_TPB / 64)) + (uint64_t)k * 64 + (threadIdx.x & 63);   // each wave its own contiguous quarter
+      if (swz & 1) i = swz_5_11(i);                // stays inside the block (both bits < log2 QSV_SBLOCK)
       if (i < n) { const cplx a = NT ? ld_nt(amp + i) : amp[i]; s = fma(a.x, a.x, fma(a.y, a.y, s)); }
     }
     s = wave_sum(s);
@@ -503,23 +504,33 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
 template <bool LDS, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict__ amp, uint64_t n, uint64_t hi, BitList q,
                                                          uint64_t fmask, uint64_t fval, const double* __restrict__ table,
-                                                         int ntab, double* __restrict__ partial, int swz) {
+                                                         int ntab, double* __restrict__ partial, int pat) {
   extern __shared__ double lds_tab[];
   if (LDS) {
     for (int i = threadIdx.x; i < ntab; i += QSV_TPB) lds_tab[i] = table[i];
     __syncthreads();
   }
   constexpr int U = 4;
-  const uint64_t stride = (uint64_t)gridDim.x * (QSV_TPB * U);
+  // A read-only stream wants long contiguous runs (profiles/r02_blocksum_variants.log: +7-9 % over a grid-stride loop of
+  // 1-KiB rows): every workgroup walks ONE contiguous chunk of the shard, every wave its own contiguous quarter of each step.
+  // (pat & 1: the index swizzle of the read+write kernels -- not for this kernel; pat & 2: the chunked walk)
+  const bool chunked = (pat & 2) != 0;
+  const uint64_t step = QSV_TPB * U;
+  const uint64_t chunk = chunked ? ((n + gridDim.x - 1) / gridDim.x + step - 1) / step * step : n;
+  const uint64_t first = chunked ? (uint64_t)blockIdx.x * chunk : (uint64_t)blockIdx.x * step;
+  const uint64_t last = chunked ? (first + chunk < n ? first + chunk : n) : n;
+  const uint64_t stride = chunked ? step : (uint64_t)gridDim.x * step;
+  const uint32_t lane_off = chunked ? (threadIdx.x >> 6) * (64 * U) + (threadIdx.x & 63) : threadIdx.x;
+  const uint32_t ustep = chunked ? 64 : QSV_TPB;
   double s0 = 0.0, s1 = 0.0;
-  for (uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x; base < n; base += stride) {
+  for (uint64_t base = first + lane_off; base - lane_off < last; base += stride) {
     cplx a[U];
     uint64_t ix[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ix[u] = base + (uint64_t)u * QSV_TPB;
-      if (swz) ix[u] = swz_5_11(ix[u]);
-      a[u] = ix[u] < n ? (NT ? ld_nt(amp + ix[u]) : amp[ix[u]]) : make_double2(0.0, 0.0);
+      ix[u] = base + (uint64_t)u * ustep;
+      if (pat & 1) ix[u] = swz_5_11(ix[u]);
+      a[u] = ix[u] < last ? (NT ? ld_nt(amp + ix[u]) : amp[ix[u]]) : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
