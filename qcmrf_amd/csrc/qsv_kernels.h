@@ -682,7 +682,7 @@ template <int K, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uint64_t nbatch,
                                                      BitIns ins, KqOffs offs,
                                                      const double* __restrict__ ur,
-                                                     const double* __restrict__ ui) {
+                                                     const double* __restrict__ ui, int chunked) {
   constexpr int D = 1 << K, MB = D / 16, KS = D / 4;
   const int lane = threadIdx.x & 63;
   const int jcol = lane & 15, kq = lane >> 4;
@@ -697,7 +697,11 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
     }
   const uint64_t wave0 = (uint64_t)blockIdx.x * (QSV_TPB / 64) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (QSV_TPB / 64);
-  for (uint64_t bt = wave0; bt < nbatch; bt += nwaves) {
+  // chunked: every wave walks its own contiguous run of batches (experiment, option kq_chunked)
+  const uint64_t per = (nbatch + nwaves - 1) / nwaves;
+  const uint64_t bt0 = chunked ? wave0 * per : wave0, bt1 = chunked ? (bt0 + per < nbatch ? bt0 + per : nbatch) : nbatch;
+  const uint64_t bstep = chunked ? 1 : nwaves;
+  for (uint64_t bt = bt0; bt < bt1; bt += bstep) {
     const uint64_t base = ins_bits(bt * 16 + jcol, ins);
     cplx v[KS];
 #pragma unroll
