@@ -501,6 +501,10 @@ __global__ __launch_bounds__(QSV_TPB) void k_marginal(const cplx* __restrict__ a
 // partial[2b+1] = sum |amp|^2 over the same indices (the conditioning mass), one pair per workgroup
 // in a fixed order (deterministic).  One read pass: 16 B per amplitude, HBM bound.
 // H = -sum theta Phi of QCMRF.py:181-193 is such an observable on the n variable qubits.
+// The table index is split: the bits a step of 1024 amplitudes varies in (address bits 0..9) are fixed per
+// (thread, u) for the whole kernel and gathered ONCE; the rest is the same for the whole workgroup row and
+// gathered in scalar registers once per step -- so an amplitude costs its load, two multiply-adds and one
+// table read, and the pass is the read stream k_blocksum is (before: 4 k 64-bit ops per amplitude).
 template <bool LDS, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict__ amp, uint64_t n, uint64_t hi, BitList q,
                                                          uint64_t fmask, uint64_t fval, const double* __restrict__ table,
@@ -511,32 +515,45 @@ __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict_
     __syncthreads();
   }
   constexpr int U = 4;
-  // A read-only stream wants long contiguous runs (profiles/r02_blocksum_variants.log: +7-9 % over a grid-stride loop of
-  // 1-KiB rows): every workgroup walks ONE contiguous chunk of the shard, every wave its own contiguous quarter of each step.
-  // (pat & 1: the index swizzle of the read+write kernels -- not for this kernel; pat & 2: the chunked walk)
+  // A read-only stream wants long contiguous runs (profiles/r02_blocksum_variants.log): with pat & 2 every workgroup
+  // walks ONE contiguous chunk of the shard and every wave its own contiguous quarter of each step.
   const bool chunked = (pat & 2) != 0;
-  const uint64_t step = QSV_TPB * U;
+  constexpr uint64_t step = QSV_TPB * U;                       // 1024 amplitudes: address bits 0..9
   const uint64_t chunk = chunked ? ((n + gridDim.x - 1) / gridDim.x + step - 1) / step * step : n;
   const uint64_t first = chunked ? (uint64_t)blockIdx.x * chunk : (uint64_t)blockIdx.x * step;
   const uint64_t last = chunked ? (first + chunk < n ? first + chunk : n) : n;
   const uint64_t stride = chunked ? step : (uint64_t)gridDim.x * step;
   const uint32_t lane_off = chunked ? (threadIdx.x >> 6) * (64 * U) + (threadIdx.x & 63) : threadIdx.x;
   const uint32_t ustep = chunked ? 64 : QSV_TPB;
+  const uint64_t lowmask = step - 1;
+  uint32_t jl[U];
+  bool okl[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t low = lane_off + (uint64_t)u * ustep;       // < 1024: the low address bits of this thread's u-th amplitude
+    uint32_t j = 0;
+    for (int b = 0; b < q.n; ++b) if (q.pos[b] < 10) j |= (uint32_t)((low >> q.pos[b]) & 1ull) << b;
+    jl[u] = j;
+    okl[u] = (low & fmask & lowmask) == (fval & lowmask);
+  }
   double s0 = 0.0, s1 = 0.0;
-  for (uint64_t base = first + lane_off; base - lane_off < last; base += stride) {
+  for (uint64_t row = first; row < last; row += stride) {      // row: a multiple of 1024, the same for the whole workgroup
     cplx a[U];
-    uint64_t ix[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ix[u] = base + (uint64_t)u * ustep;
-      if (pat & 1) ix[u] = swz_5_11(ix[u]);
-      a[u] = ix[u] < last ? (NT ? ld_nt(amp + ix[u]) : amp[ix[u]]) : make_double2(0.0, 0.0);
+      const uint64_t i = row + lane_off + (uint64_t)u * ustep;
+      a[u] = i < last ? (NT ? ld_nt(amp + i) : amp[i]) : make_double2(0.0, 0.0);
     }
+    const uint64_t g = hi | row;                               // wave-uniform: scalar registers
+    const uint32_t glo = __builtin_amdgcn_readfirstlane((uint32_t)g), ghi = __builtin_amdgcn_readfirstlane((uint32_t)(g >> 32));
+    const uint64_t gs = ((uint64_t)ghi << 32) | glo;
+    uint32_t jh = 0;
+    for (int b = 0; b < q.n; ++b) if (q.pos[b] >= 10) jh |= (uint32_t)((gs >> q.pos[b]) & 1ull) << b;
+    const bool okh = (gs & fmask & ~lowmask) == (fval & ~lowmask);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t g = hi | ix[u];
-      const double p = ((g & fmask) == fval) ? fma(a[u].x, a[u].x, a[u].y * a[u].y) : 0.0;
-      const uint32_t j = gather_bits(g, q);
+      const double p = (okh && okl[u]) ? fma(a[u].x, a[u].x, a[u].y * a[u].y) : 0.0;
+      const uint32_t j = jh | jl[u];
       const double t = LDS ? lds_tab[j] : table[j];
       s0 = fma(p, t, s0);
       s1 += p;
