@@ -1,7 +1,8 @@
 """GPU box: do read+write k_multi passes like their register targets on the TOP bits of a big shard
 (as the write-only generator does)?"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qcmrf_amd import _lib, ir, program
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 34
@@ -12,7 +13,7 @@ def rx():
 eng = _lib.Engine(W)
 eng.init_uniform((1 << W) - 1)
 def run(regs, bor, stat, init, label):
-    sel = [12, 13]
+    sel = [q for q in (25, 26, 19, 21) if q not in regs + bor + stat][:2]
     mux = lambda t: ir.op_mux(sel, t, np.array([rx() for _ in range(4)]))
     quiet = (1 << W) - 1
     for q in regs + bor + stat:
@@ -36,7 +37,15 @@ cases = [
     (R(T - 4, T), [14, 15, 16], [0, 1, 2], "reg top 5 + bor 14-16 + stat 0-2"),
     (R(6, 10), [11, 12 + 2, 15], [0, 1, 2], "reg 6-10 + bor 11,14,15 + stat 0-2"),
     (R(T - 4, T), [6, 7, 8], [], "reg top 5 + bor 6-8"),
+    # round 2 (non-temporal kernels, generalised lane map): mixed tiles
+    ([6] + R(T - 3, T), [], [], "reg 6 + top 4"),
+    ([6, 7] + R(T - 2, T), [], [], "reg 6,7 + top 3"),
+    ([12] + R(T - 3, T), [], [], "reg 12 + top 4"),
+    (R(14, 18), [], [], "reg 14-18"),
+    (R(20, 24), [], [], "reg 20-24"),
+    (R(T - 4, T), [12, 13, 14], [0, 1, 2], "reg top 5 + bor 12-14 + stat 0-2"),
+    (R(T - 4, T), [11, 12, 13], [], "reg top 5 + bor 11-13"),
 ]
-for init in (False, True):
+for init in ((False,) if os.environ.get('QSV_RW_ONLY') else (False, True)):
     for regs, bor, stat, label in cases:
         run(regs, bor, stat, init, label)
