@@ -251,18 +251,21 @@ class QuantumCircuit:
                              % (instruction.name, instruction.num_qubits, len(qs)))
         return self._add(instruction, qs, cs)
 
-    def inverse(self):
+    def inverse(self, _shared=None):
+        """_shared (not in Qiskit's signature): a dict a caller that inverts several circuits built from the
+        same sub-circuit objects may pass, so that one definition object has ONE inverse among all of them"""
         inv = QuantumCircuit(self.num_qubits, self.num_clbits, name=self.name + "_dg",
                              global_phase=-self.global_phase)
-        inverted = {}                    # instructions that share one definition share its inverse too
+        inverted = _shared if _shared is not None else {}   # instructions that share one definition share its inverse too
         for ci in reversed(self.data):
             qs = [inv.qubits[self._qindex[id(q)]] for q in ci.qubits]
             cs = [inv.clbits[self._cindex[id(c)]] for c in ci.clbits]
             op = ci.operation
             if op.definition is not None:
-                d = inverted.get(id(op.definition))
-                if d is None:
-                    d = inverted[id(op.definition)] = op.definition.inverse()
+                hit = inverted.get(id(op.definition))
+                if hit is None:
+                    hit = inverted[id(op.definition)] = (op.definition, op.definition.inverse())   # the key object stays alive with its id
+                d = hit[1]
                 inv._add(Instruction(op.name + "_dg", op.num_qubits, op.num_clbits, op.params, d), qs, cs)
             else:
                 inv._add(op.inverse(), qs, cs)

@@ -330,7 +330,13 @@ def _emit_phase_block(definition, qmap, out):
         d = getattr(o, "definition", None)
         if d is None or getattr(o, "condition", None) is not None:
             return False
-        ak = prev_k if d is prev_d else _and_key(d)         # compute / uncompute often share one definition object
+        if d is prev_d:                                     # compute / uncompute share one definition object
+            ak = prev_k
+        else:                                               # ... and so may many blocks of one circuit: read each object once per walk
+            memo = out._and_memo
+            ak = memo.get(id(d), memo)
+            if ak is memo:
+                ak = memo[id(d)] = _and_key(d)
         if ak is None:
             return False
         prev_d, prev_k = d, ak
@@ -579,6 +585,7 @@ def ingest(circuit, peephole=False, keep_measures=False):
     out.keep_measures = bool(keep_measures)
     out._measured = set()
     out._phase_blocks = []
+    out._and_memo = {}               # id(definition) -> signature, for THIS walk only (the objects are alive throughout)
     if not (peephole and not keep_measures and _walk_flat(circuit, out)):
         _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
     _finish_phase_blocks(out)
