@@ -206,14 +206,17 @@ __device__ __forceinline__ int multi_jr(const MultiOp& op, int j) {
   return jr;
 }
 
-#define QSV_OPQ(x) ({ int _t = (x); asm volatile("" : "+s"(_t)); _t; })   // re-hide a scalar before every test (rule 2)
+#define QSV_OPQ(x) ({ int _t = (x); asm volatile("" : "+s"(_t)); _t; })
+// the control part of an op, read in ONE scalar load batch at the top of gen_op (it used to be three dependent
+// ones: shape / bit, then the masks inside the shape's branch, then the fire mask behind the exec test)
+struct GenCtl { uint64_t tmask, tval; uint32_t flo, fhi; int bit; };   // re-hide a scalar before every test (rule 2)
 // does amplitude j fire?  32-bit halves of the host-made mask: one s_bitcmp1_b32 + branch per test, firing path in line
 #define QSV_FIRES(flo, fhi, j) __builtin_expect(((((j) < 32 ? (flo) : (fhi)) >> ((j) & 31)) & 1u) != 0u, 1)
 #define QSV_PAIR(p, B) const int j0 = (((p) >> (B)) << ((B) + 1)) | ((p) & ((1 << (B)) - 1)), j1 = j0 | (1 << (B))
 
 // gate of a general pass on register bit B
 template <int R, int B>
-__device__ __forceinline__ void gen_gate(cplx (&a)[1 << R], const MultiOp& op, int shape, uint64_t base,
+__device__ __forceinline__ void gen_gate(cplx (&a)[1 << R], const MultiOp& op, int shape, const GenCtl& ctl, uint64_t base,
                                          const cplx* __restrict__ lt) {
   constexpr int NP = 1 << (R - 1);
   if (QSV_OPQ(shape) < GS_X) {
@@ -234,8 +237,8 @@ __device__ __forceinline__ void gen_gate(cplx (&a)[1 << R], const MultiOp& op, i
     }
   }
   if (QSV_OPQ(shape) >= GS_X) {
-    if ((base & op.tmask) == op.tval) {                  // exec-masked: a wave without a matching lane skips the op
-      const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+    if ((base & ctl.tmask) == ctl.tval) {                // exec-masked: a wave without a matching lane skips the op
+      const uint32_t flo = ctl.flo, fhi = ctl.fhi;
       if (QSV_OPQ(shape) == GS_X) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) { QSV_PAIR(p, B); if (QSV_FIRES(flo, fhi, j0)) swap_inplace(a[j0], a[j1]); }
@@ -252,7 +255,7 @@ __device__ __forceinline__ void gen_gate(cplx (&a)[1 << R], const MultiOp& op, i
 
 // op of a general pass without a register target
 template <int R>
-__device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, int shape, uint64_t base,
+__device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, int shape, const GenCtl& ctl, uint64_t base,
                                          const cplx* __restrict__ lt) {
   if (QSV_OPQ(shape) < GS_LTAB_T) {
     if (QSV_OPQ(shape) == GS_DIAG_T) {
@@ -266,9 +269,9 @@ __device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, i
       for (int j = 0; j < (1 << R); ++j) cmul_inplace(a[j], lt[op.tab + jt + multi_jr<R>(op, j)]);
     }
     if (QSV_OPQ(shape) == GS_PHASE) {
-      if ((base & op.tmask) == op.tval) {
+      if ((base & ctl.tmask) == ctl.tval) {
         const cplx ph = make_double2(op.m[0], op.m[1]);
-        const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+        const uint32_t flo = ctl.flo, fhi = ctl.fhi;
 #pragma unroll
         for (int j = 0; j < (1 << R); ++j)
           if (QSV_FIRES(flo, fhi, j)) cmul_inplace_s(a[j], ph);
@@ -300,9 +303,9 @@ __device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, i
       // tmask never contains the target bit, so a lane and its partner fire together.  No exec-masked
       // branch here (the shuffles need every lane on): a lane whose controls do not match reads ITSELF
       // (X) or mixes with the identity (matrix); a wave without any matching lane skips the op.
-      const bool ct = (base & op.tmask) == op.tval;
+      const bool ct = (base & ctl.tmask) == ctl.tval;
       if (QSV_OPQ(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(ct) != 0)))) {
-        const uint32_t flo = (uint32_t)op.rfire, fhi = (uint32_t)(op.rfire >> 32);
+        const uint32_t flo = ctl.flo, fhi = ctl.fhi;
         // no control on a register bit (the usual case): one block without tests, so the 2^R x 4
         // shuffles are in flight together instead of one amplitude's at a time
         const int all = __builtin_amdgcn_readfirstlane(op.uniform);
@@ -340,24 +343,33 @@ __device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, i
 template <int R>
 __device__ __forceinline__ void gen_op(cplx (&a)[1 << R], const MultiOp& op, uint64_t base, const cplx* __restrict__ lt) {
   const int shape = __builtin_amdgcn_readfirstlane(op.shape);
+  GenCtl ctl;
+  {
+    uint32_t tml = (uint32_t)op.tmask, tmh = (uint32_t)(op.tmask >> 32), tvl = (uint32_t)op.tval, tvh = (uint32_t)(op.tval >> 32);
+    uint32_t fl = (uint32_t)op.rfire, fh = (uint32_t)(op.rfire >> 32);
+    int bit0 = op.bit;
+    asm volatile("" : "+s"(tml), "+s"(tmh), "+s"(tvl), "+s"(tvh), "+s"(fl), "+s"(fh), "+s"(bit0));   // here, not where first used
+    ctl.bit = bit0;
+    ctl.tmask = ((uint64_t)tmh << 32) | tml; ctl.tval = ((uint64_t)tvh << 32) | tvl; ctl.flo = fl; ctl.fhi = fh;
+  }
   if (QSV_OPQ(shape) < GS_DIAG_T) {
     if constexpr (R > 0) {
-      const int b = __builtin_amdgcn_readfirstlane(op.bit);
+      const int b = ctl.bit;
       if (QSV_OPQ(b) < 2) {
-        if (QSV_OPQ(b) == 0) gen_gate<R, 0>(a, op, shape, base, lt);
-        if constexpr (R > 1) if (QSV_OPQ(b) == 1) gen_gate<R, 1>(a, op, shape, base, lt);
+        if (QSV_OPQ(b) == 0) gen_gate<R, 0>(a, op, shape, ctl, base, lt);
+        if constexpr (R > 1) if (QSV_OPQ(b) == 1) gen_gate<R, 1>(a, op, shape, ctl, base, lt);
       }
       if constexpr (R > 2) {
         if (QSV_OPQ(b) >= 2) {
-          if (QSV_OPQ(b) == 2) gen_gate<R, 2>(a, op, shape, base, lt);
-          if constexpr (R > 3) if (QSV_OPQ(b) == 3) gen_gate<R, 3>(a, op, shape, base, lt);
-          if constexpr (R > 4) if (QSV_OPQ(b) == 4) gen_gate<R, 4>(a, op, shape, base, lt);
-          if constexpr (R > 5) if (QSV_OPQ(b) == 5) gen_gate<R, 5>(a, op, shape, base, lt);
+          if (QSV_OPQ(b) == 2) gen_gate<R, 2>(a, op, shape, ctl, base, lt);
+          if constexpr (R > 3) if (QSV_OPQ(b) == 3) gen_gate<R, 3>(a, op, shape, ctl, base, lt);
+          if constexpr (R > 4) if (QSV_OPQ(b) == 4) gen_gate<R, 4>(a, op, shape, ctl, base, lt);
+          if constexpr (R > 5) if (QSV_OPQ(b) == 5) gen_gate<R, 5>(a, op, shape, ctl, base, lt);
         }
       }
     }
   }
-  if (QSV_OPQ(shape) >= GS_DIAG_T) gen_list<R>(a, op, shape, base, lt);
+  if (QSV_OPQ(shape) >= GS_DIAG_T) gen_list<R>(a, op, shape, ctl, base, lt);
 }
 
 // Schedule of a TABLE-OP pass (MODE 1, 2): the host lays the gates out in ROUNDS of 1 + R slots.
