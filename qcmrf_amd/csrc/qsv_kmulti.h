@@ -457,7 +457,7 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
       bool all_dead = R > 0;
 #pragma unroll
       for (int c = 0; c < R; ++c) all_dead = all_dead && (ob[c] & nonmask);
-      if (all_dead && nrounds > 0) {
+      if (all_dead && nrounds > 0 && need_tables) {           // (a workgroup that staged no tables holds zeros only: nothing to apply)
         const MultiSlot sl = slots[0];
         for (int d = 0; d < sl.ndiag; ++d) {
           const MultiOp& op = ops[sl.first + d];
