@@ -119,6 +119,11 @@ int qsv_rccl_selftest(int device_id, uint64_t n_doubles);
  * amplitudes over a 2^n_qubits shard, verified element by element.  0 on success. */
 int qsv_rccl_exchange_selftest(int device_id, int n_qubits, int chunk_log2);
 
+/* Diagnostic: leave quiet NaNs in the LDS of every compute unit of the handle's devices (LDS is not cleared
+ * between kernels).  A kernel that reads a table it never staged then produces NaN deterministically instead
+ * of "usually fine" -- used by the GPU tests before the init passes, whose idle workgroups skip the staging. */
+int qsv_poison_lds(qsv_handle* h);
+
 int qsv_destroy(qsv_handle* h);
 int qsv_sync(qsv_handle* h);
 

@@ -95,6 +95,7 @@ SIGNATURES = {
     "qsv_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qsv_rccl_selftest": (C.c_int, [C.c_int, C.c_uint64]),
     "qsv_rccl_exchange_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "qsv_poison_lds": (C.c_int, [C.c_void_p]),
     "qsv_device_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "qsv_ipc_export": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "qsv_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_char_p, C.c_int]),
@@ -278,6 +279,10 @@ class Engine:
 
     def sync(self):
         _chk(self._lib.qsv_sync(self._h))
+
+    def poison_lds(self):
+        """diagnostic: quiet NaNs into the LDS of every compute unit (qsv_poison_lds)"""
+        _chk(self._lib.qsv_poison_lds(self._h))
 
     def set_option(self, name, value):
         _chk(self._lib.qsv_set_option(self._h, name.encode(), int(value)))

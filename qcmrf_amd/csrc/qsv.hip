@@ -563,6 +563,22 @@ extern "C" int qsv_rccl_selftest(int device_id, uint64_t n_doubles) {
   return rc;
 }
 
+extern "C" int qsv_poison_lds(qsv_handle* h) {
+  if (!h) return fail(QSV_E_BADARG, "NULL handle");
+  for (Shard& s : h->shards) {
+    CHK(shard_set(s));
+    unsigned long long* sink = nullptr;
+    HIPCHK(hipMalloc(&sink, sizeof *sink));
+    // 52 KiB per workgroup: exactly three fit a compute unit's 160 KiB, and 3 x CUs workgroups that all stay resident
+    // (the spin) land three on every unit
+    hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)s.n_cu * 3), dim3(QSV_TPB), 52 * 1024, s.stream, sink, 52 * 1024 / 8, 4000);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.stream));
+    HIPCHK(hipFree(sink));
+  }
+  return QSV_OK;
+}
+
 extern "C" int qsv_sync(qsv_handle* h) {
   if (!h) return fail(QSV_E_BADARG, "NULL handle");
   for (Shard& s : h->shards) {

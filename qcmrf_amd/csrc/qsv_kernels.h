@@ -326,6 +326,18 @@ __global__ __launch_bounds__(QSV_TPB) void k_unpack_block(cplx* __restrict__ amp
     amp[ins_bits(p0 + q, ins) | fixed] = buf[q];
 }
 
+// diagnostic (qsv_poison_lds): fill this workgroup's LDS with quiet NaNs and stay long enough for the
+// whole grid to be resident at once, so that every compute unit gets its share
+__global__ __launch_bounds__(QSV_TPB) void k_poison_lds(unsigned long long* __restrict__ sink, int ndouble, int spin) {
+  extern __shared__ double4 lds_raw[];
+  double* b = reinterpret_cast<double*>(lds_raw);
+  for (int i = threadIdx.x; i < ndouble; i += QSV_TPB) b[i] = __longlong_as_double(0x7ff8000000000001ll);
+  __syncthreads();
+  unsigned long long acc = 0;
+  for (int k = 0; k < spin; ++k) acc += (unsigned long long)__double_as_longlong(b[(threadIdx.x + k) % ndouble]) >> 60;
+  if (acc == 1) sink[0] = acc;                               // never true (>= 7 per step): keeps the loop alive
+}
+
 // ---------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------

@@ -152,6 +152,24 @@ def test_extract_probs_pipeline(be, models):
     assert abs(delta - Z / 2 ** qc.num_vertices) < 0.01
 
 
+@pytest.mark.parametrize("fusion,fold", [(2, True), (3, False), (1, True), (0, True)])
+def test_init_passes_never_read_a_table_they_did_not_stage(be, fusion, fold):
+    """Workgroups of an init pass that start from zeros skip staging the gate tables into LDS.  LDS is not
+    cleared between kernels, so a read of an unstaged table is 'usually fine' (finite garbage times zero) --
+    an early version did exactly that in the scalar shortcut of the first round and produced NaN once in a
+    while.  With quiet NaNs left in every compute unit's LDS first (qsv_poison_lds) it fails every time."""
+    from qcmrf_amd import QCMRF
+    C = gs.chain_cliques(10)
+    th = random_theta(36)
+    be.run(QCMRF([[0, 1]], [-0.1] * 4), shots=0)                 # make sure the engine of this width exists below
+    amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, fold_fresh=fold)
+    for _ in range(3):
+        be.last_engine.poison_lds()
+        amp, meta = run_state(be, QCMRF(C, th), fusion=fusion, fold_fresh=fold)
+        assert not np.isnan(amp).any()
+        assert np.abs(amp - cf.amplitudes(C, th)).max() < 1e-12
+
+
 def _full_size_properties(be, C, **opts):
     """size-independent checks at sizes no oracle can hold: norm = 1; P(all ancillas 0) = Z/2^n;
     P(x | ancillas 0) = Gibbs pmf (1e-10); random amplitude slices (incl. the very top of the
