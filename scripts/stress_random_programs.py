@@ -10,7 +10,7 @@ from oracle.sharded_numpy import NumpyEngine
 
 
 
-def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14, 15, 16, 17)):
+def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14, 15, 16, 17), poison=False):
     """returns the number of mismatching programs.  widths: state sizes drawn from; at >= 21 qubits the
     workgroups of a pass no longer run all at once (in-place permutations that cross workgroups show)"""
     rs = np.random.RandomState(seed)
@@ -92,6 +92,8 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
             ref.init_uniform((1 << W) - 1)
             eng.init_uniform((1 << W) - 1)
         ref.exec(rec, data)
+        if poison:
+            eng.poison_lds()                              # quiet NaNs in every compute unit's LDS: a read of an unstaged table shows
         eng.exec(rec, data)
         want = ref.amplitudes()
         got = eng.amplitudes()
@@ -112,7 +114,11 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "big" else None
+    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("big", "poison") else None
+    if len(sys.argv) > 3 and sys.argv[3] == "poison":       # N SEED poison: LDS poisoned before every program
+        bad = run(n, int(sys.argv[2]), poison=True)
+        print("done: %d cases, %d mismatches" % (n, bad))
+        sys.exit(1 if bad else 0)
     if len(sys.argv) > 3 and sys.argv[3] == "big":          # N SEED big: wide states
         bad = run(n, int(sys.argv[2]), widths=(21, 22, 23))
         print("done: %d cases, %d mismatches" % (n, bad))
