@@ -269,7 +269,8 @@ int qsv_timer_end(qsv_handle* h, double* ms);
  *   memory      nontemporal [-1], multi_nt [-1], init_prod_nt [-1]   non-temporal loads/stores: -1 by shard size, 0 never, 1 always
  *   measurement cache_sums [1], fused_sums [1]   keep / produce per-tile |amp|^2 sums in the last pass of a program
  *   kernels     unroll [4], lowt_shuffle [1], pair_variant [0], kq_mfma [1], blocks_per_cu [65536]
- *               swizzle [1]        one-gate kernels: lane bit 5 of a wave access carries address bit 11 (two 512-byte runs 32 KiB apart)
+ *               swizzle [1]        one-gate kernels: lane bit 5 of a wave access carries address bit 11 (two 512-byte runs 32 KiB apart);
+ *                                  1 from 2^26 amplitudes per shard, 2 from 2^14, 0 never        lane_map_min_l [26]  same for k_multi tiles other than bits 6..10
  *   other       zero_tracking [0]  skip amplitudes known to be zero (opt-in)       exchange_chunk_log2 [24]  amplitudes per exchange chunk */
 int qsv_set_option(qsv_handle* h, const char* name, int value);
 

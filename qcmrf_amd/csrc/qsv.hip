@@ -194,6 +194,7 @@ struct qsv_handle {
   int opt_init_prod_r = 0;            // amplitudes per thread of the generator, log2: 0 by shard size (default), else 3..6
   int opt_init_prod = 1;              // init followed by diagonals only -> k_init_prod (write-only generator)
   int opt_pass_hints = 1;             // honour QSV_OPF_NEW_PASS (planner-chosen pass boundaries)
+  int opt_lane_map_min_l = 26;        // local qubits from which the lane map is applied to tiles other than bits 6..10
   int opt_lane_map = 1;               // access pattern of passes without borrowed lanes: 0 plain, 1 auto, else explicit 5-bit fields
   int opt_dyn_lanes = 3;              // lane bits 3..5 lent per pass to targets anywhere below bit 28 (0..3)
   int opt_cache_sums = 1;             // 0: every norm / sample recomputes the block sums (benchmarks)

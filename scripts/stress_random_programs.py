@@ -79,7 +79,8 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
                 "xframe": int(rs.choice([1, 1, 0])), "multi_nt": int(rs.choice([-1, 1, 0])),
                 "init_prod_nt": int(rs.choice([-1, 1])), "pass_budget": int(rs.choice([0, 0, 30, 100])),
                 "general_r": int(rs.choice([4, 4, 5, 3, 2, 1])), "general_light_r": int(rs.choice([5, 5, 4, 3])),
-                "pass_max_ops": int(rs.choice([64, 64, 8, 200]))}
+                "pass_max_ops": int(rs.choice([64, 64, 8, 200])), "swizzle": int(rs.choice([1, 2, 2, 0])),
+                "lane_map_min_l": int(rs.choice([26, 14, 14]))}
         if only is not None and (case != only if only >= 0 else case < -only):
             continue                                       # replay mode (CASE, or -CASE: from that case on): the generator state advances, nothing runs
         if override:
