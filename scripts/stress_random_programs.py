@@ -106,6 +106,8 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
             bad += 1
             print("MISMATCH case %d W=%d P=%d style=%d err=%.3e normerr=%.3e opts=%s" % (case, W, P, style, err, nerr, opts), flush=True)
             print("   ops:", [repr(o) + ("*" if o.new_pass else "") for o in ops], flush=True)
+        if verbose and min(widths) >= 24:
+            print("case %d W=%d P=%d ok so far (%d mismatches)" % (case, W, P, bad), flush=True)     # slow cases: keep the log alive
         if case % 50 == 49 and verbose:
             print("... %d cases, %d mismatches" % (case + 1, bad), flush=True)
     for e in engines.values():
@@ -115,9 +117,13 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("big", "poison") else None
+    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("big", "poison", "huge") else None
     if len(sys.argv) > 3 and sys.argv[3] == "poison":       # N SEED poison: LDS poisoned before every program
         bad = run(n, int(sys.argv[2]), poison=True)
+        print("done: %d cases, %d mismatches" % (n, bad))
+        sys.exit(1 if bad else 0)
+    if len(sys.argv) > 3 and sys.argv[3] == "huge":         # N SEED huge: 26-27 qubits -- the size-gated forms (non-temporal, swizzle, lane map) with random gates
+        bad = run(n, int(sys.argv[2]), widths=(26, 26, 27))
         print("done: %d cases, %d mismatches" % (n, bad))
         sys.exit(1 if bad else 0)
     if len(sys.argv) > 3 and sys.argv[3] == "big":          # N SEED big: wide states
