@@ -237,10 +237,11 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq(cplx* __restrict__ amp, uint64_t
 // layout: swap two local bit positions (a < b): amp[..1_a..0_b..] <-> amp[..0_a..1_b..]
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(QSV_TPB) void k_swap_bits(cplx* __restrict__ amp, uint64_t nq,
-                                                       BitIns ins, uint64_t abit, uint64_t bbit) {
+                                                       BitIns ins, uint64_t abit, uint64_t bbit, int swz) {
   const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
   for (uint64_t p = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; p < nq; p += stride) {
-    const uint64_t i = ins_bits(p, ins);
+    uint64_t i = ins_bits(p, ins);
+    if (swz) i = swz_5_11(i);                              // neither swapped bit is bit 5 or 11 (host)
     const cplx x = amp[i | abit], y = amp[i | bbit];
     amp[i | abit] = y;
     amp[i | bbit] = x;
