@@ -304,10 +304,11 @@ __global__ __launch_bounds__(QSV_TPB) void k_unpack(cplx* __restrict__ amp, cons
 // spell B.  `ins` = the k local bit positions (sorted), a block = the 2^(L-k) amplitudes
 // ins_bits(p) | fixed.  In place between two mapped shards:
 __global__ __launch_bounds__(QSV_TPB) void k_swap_blocks(cplx* __restrict__ A, cplx* __restrict__ B, uint64_t p0,
-                                                         uint64_t cnt, BitIns ins, uint64_t fa, uint64_t fb) {
+                                                         uint64_t cnt, BitIns ins, uint64_t fa, uint64_t fb, int swz) {
   const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
   for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
-    const uint64_t i = ins_bits(p0 + q, ins);
+    uint64_t i = ins_bits(p0 + q, ins);
+    if (swz) i = swz_5_11(i);       // a bijection of the block's index space (bits 5, 11 are not swapped bits): ranks that split [0, cnt) still split the block
     const cplx x = A[i | fa], y = B[i | fb];
     A[i | fa] = y;
     B[i | fb] = x;
