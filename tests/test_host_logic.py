@@ -557,3 +557,24 @@ def test_qiskit_shaped_lowered_circuits_come_back_as_one_multiplexer_per_clique(
         assert all(len(o.ctrls) == 3 for o in pl.ops if o.kind == "mux")            # two variables + the AND scratch qubit
         ing, pl = be.compile(t)                                                       # fold_fresh: init x diagonal factors only
         assert set(_kinds(pl.ops)) == {"init", "diag"}, _kinds(pl.ops)
+
+
+def test_gate_by_gate_programs_keep_masked_targets_off_the_lane_bits():
+    """planner.choose_layout, general policy: in a program made mostly of controlled X / phase / 2x2 ops (the
+    reference's stream at fusion 0) the lane bits (physical 0..5) go to the qubits that are the target of the
+    FEWEST such ops -- a controlled X costs 31 us on a register bit and 74 us on a lane bit of a general pass,
+    an uncontrolled X nothing anywhere -- and the fused forms of the same circuit keep the round-1 layout."""
+    from qcmrf_amd import QCMRF, workloads as wl
+    from qcmrf_amd.backend import QsvBackend
+    for W in (20, 28, 34):
+        C = wl.for_width(W)
+        qc = QCMRF(C, wl.theta_halfnorm(wl.dimension(C)))
+        ing, pl = QsvBackend().compile(qc, fusion=0)
+        ccx = [o for o in pl.ops if o.kind == "x" and len(o.ctrls) > 0]
+        assert ccx and all(o.target >= 6 for o in ccx), W
+        # the AND scratch qubit, target of every CCX, sits right above the lanes
+        assert len({o.target for o in ccx}) == 1 and ccx[0].target <= 8
+        # a permutation of the qubits, whatever the policy
+        assert sorted(pl.layout) == list(range(qc.num_qubits))
+        ing3, pl3 = QsvBackend().compile(qc, fusion=3)
+        assert all(o.kind in ("init", "diag") for o in pl3.ops)
