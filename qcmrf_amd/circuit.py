@@ -74,8 +74,10 @@ class Instruction:
 
     def inverse(self):
         if self.definition is not None:
-            return Instruction(self.name + "_dg", self.num_qubits, self.num_clbits, self.params,
-                               self.definition.inverse())
+            name = self.name[:-3] if self.name.endswith("_dg") else self.name + "_dg"
+            inv = self.definition.inverse()
+            inv.name = name
+            return Instruction(name, self.num_qubits, self.num_clbits, self.params, inv)
         if self.name.startswith("mcx"):
             return Instruction(self.name, self.num_qubits)
         if self.name in _STANDARD:
@@ -251,24 +253,15 @@ class QuantumCircuit:
                              % (instruction.name, instruction.num_qubits, len(qs)))
         return self._add(instruction, qs, cs)
 
-    def inverse(self, _shared=None):
-        """_shared (not in Qiskit's signature): a dict a caller that inverts several circuits built from the
-        same sub-circuit objects may pass, so that one definition object has ONE inverse among all of them"""
+    def inverse(self):
+        """same bits, name + '_dg', negated global phase, every operation inverted on its own in reverse
+        order (qiskit.QuantumCircuit.inverse takes no arguments either)"""
         inv = QuantumCircuit(self.num_qubits, self.num_clbits, name=self.name + "_dg",
                              global_phase=-self.global_phase)
-        inverted = _shared if _shared is not None else {}   # instructions that share one definition share its inverse too
         for ci in reversed(self.data):
             qs = [inv.qubits[self._qindex[id(q)]] for q in ci.qubits]
             cs = [inv.clbits[self._cindex[id(c)]] for c in ci.clbits]
-            op = ci.operation
-            if op.definition is not None:
-                hit = inverted.get(id(op.definition))
-                if hit is None:
-                    hit = inverted[id(op.definition)] = (op.definition, op.definition.inverse())   # the key object stays alive with its id
-                d = hit[1]
-                inv._add(Instruction(op.name + "_dg", op.num_qubits, op.num_clbits, op.params, d), qs, cs)
-            else:
-                inv._add(op.inverse(), qs, cs)
+            inv._add(ci.operation.inverse(), qs, cs)
         return inv
 
 
@@ -279,12 +272,15 @@ def AND(num_variable_qubits, flags=None):
     flags = list(flags) if flags is not None else [1] * num_variable_qubits
     if len(flags) != num_variable_qubits:
         raise ValueError("AND: %d flags for %d variables" % (len(flags), num_variable_qubits))
-    circ = QuantumCircuit(num_variable_qubits + 1, name="and")
+    inner = QuantumCircuit(num_variable_qubits + 1, name="and")
     ctrl = [q for q, f in enumerate(flags) if f != 0]
     flip = [q for q, f in enumerate(flags) if f < 0]
     if flip:
-        circ.x(flip)
-    circ.mcx(ctrl, num_variable_qubits)
+        inner.x(flip)
+    inner.mcx(ctrl, num_variable_qubits)
     if flip:
-        circ.x(flip)
+        inner.x(flip)
+    # nested as Qiskit nests it: the AND circuit holds ONE gate "and" whose definition is x.. mcx x..
+    circ = QuantumCircuit(num_variable_qubits + 1, name="and")
+    circ.append(inner.to_gate(), list(range(num_variable_qubits + 1)))
     return circ

@@ -42,6 +42,11 @@ def _index_of(circuit, bit, cache):
     return cache[k]
 
 
+def _cbit(circuit, ci_map, bit, cache):
+    i = ci_map.get(id(bit)) if ci_map is not None else None
+    return _index_of(circuit, bit, cache) if i is None else i
+
+
 def _bit_maps(circuit):
     """id(bit) -> index for the circuit's qubits and clbits (one pass; find_bit only as fallback)"""
     qs = getattr(circuit, "qubits", None)
@@ -167,12 +172,37 @@ def _flat(definition):
         return [ci[0] for ci in data], [ci[1] for ci in data]
 
 
+def _unwrap(definition):
+    """Qiskit nests its library circuits: ``AND(...)`` is a circuit holding ONE gate "and" on all of its qubits
+    whose definition is the X..X . MCX . X..X, and ``append(circuit)`` wraps that once more (to_instruction).
+    Follow such single-instruction wrappers (same qubits, same order, no condition, no phase) down to the
+    definition that has the content; primitives are never opened (an ``x`` has a definition too: u3)."""
+    for _ in range(8):
+        data = definition.data
+        if len(data) != 1:
+            break
+        ci = data[0]
+        try:
+            op, qargs = ci.operation, ci.qubits
+        except AttributeError:
+            op, qargs, _ = ci
+        if op.name in _PRIMITIVES or getattr(op, "condition", None) is not None:
+            break
+        inner = getattr(op, "definition", None)
+        # list == list compares element identity first: no Bit.__eq__ call when the bits are the circuit's own
+        if inner is None or getattr(definition, "global_phase", 0) or list(qargs) != list(definition.qubits):
+            break
+        definition = inner
+    return definition
+
+
 def _and_key(definition):
-    """Structural signature of a small flat definition -- per instruction (name, unconditioned?,
-    qubit positions...), plus the control state of the middle gate -- or None if it cannot be
-    X..X . MCX . X..X.  Hot: a 34-qubit QCMRF circuit has 304 AND instances (two per clique state,
-    QCMRF.py:225,227) but only 4 distinct signatures; everything beyond reading the signature off
+    """Structural signature of a small flat definition -- gate names, qubit positions in instruction
+    order, the control state of the middle gate -- or None if it cannot be X..X . MCX . X..X.
+    Hot: a 34-qubit QCMRF circuit has 304 AND instances (two per clique state, QCMRF.py:225,227), every
+    one a distinct object, but only 4 distinct signatures; everything beyond reading the signature off
     the object is memoised on it."""
+    definition = _unwrap(definition)
     data = definition.data
     n = len(data)
     if not n & 1 or n > 33 or getattr(definition, "global_phase", 0):
@@ -180,13 +210,21 @@ def _and_key(definition):
     qs = getattr(definition, "qubits", None)
     if qs is None:
         return None
-    ix = qs.index
     try:
-        sig = tuple([(ci.operation.name, ci.operation.condition is None, *map(ix, ci.qubits)) for ci in data])
-    except AttributeError:                                   # tuple-style instructions / no .condition attribute
-        ops, qargs = _flat(definition)
-        sig = tuple([(o.name, getattr(o, "condition", None) is None, *map(ix, qa)) for o, qa in zip(ops, qargs)])
-    return sig, getattr(_unpack(data[n >> 1])[0], "ctrl_state", None)
+        rows = [(ci.operation, ci.qubits) for ci in data]
+    except AttributeError:                                   # tuple-style instructions
+        rows = [(ci[0], ci[1]) for ci in data]
+    try:
+        if any([o.condition for o, _ in rows]):
+            return None
+    except AttributeError:                                   # no .condition attribute at all (Qiskit >= 2)
+        pass
+    ix = dict(zip(map(id, qs), range(len(qs))))
+    try:
+        pos = tuple([ix[id(q)] for _, qa in rows for q in qa])
+    except KeyError:                                         # bits that are equal to, but not, the definition's own
+        pos = tuple([qs.index(q) for _, qa in rows for q in qa])
+    return tuple([o.name for o, _ in rows]), pos, getattr(rows[n >> 1][0], "ctrl_state", None)
 
 
 _SHAPES = {}
@@ -199,18 +237,16 @@ def _shape_of_key(key):
         return _SHAPES[key]
     except KeyError:
         pass
-    sig, state = key
-    n = len(sig)
+    names, pos, state = key
+    n = len(names)
     f = n >> 1
     res = None
-    mid = sig[f]
-    sides = sig[:f] + sig[f + 1:]
-    if (mid[0] in _MCX_SET and all(e[1] for e in sig) and len(mid) >= 3
-            and all(e[0] == "x" and len(e) == 3 for e in sides)):
-        head, tail = [e[2] for e in sig[:f]], [e[2] for e in sig[f + 1:]]
-        ctrls, tgt = list(mid[2:-1]), mid[-1]
+    # sides: f one-qubit X gates each; the middle gate owns the positions between them
+    if names[f] in _MCX_SET and all(nm == "x" for nm in names[:f] + names[f + 1:]) and len(pos) >= 2 * f + 1:
+        head, mid, tail = list(pos[:f]), pos[f:len(pos) - f], list(pos[len(pos) - f:])
+        ctrls, tgt = list(mid[:-1]), mid[-1]
         vals = [1] * len(ctrls) if state is None else [(int(state) >> i) & 1 for i in range(len(ctrls))]
-        if (sorted(head) == sorted(tail) and len(set(head)) == f and len(set(mid[2:])) == len(mid) - 2
+        if (sorted(head) == sorted(tail) and len(set(head)) == f and len(set(mid)) == len(mid)
                 and tgt not in head and all(x in ctrls for x in head)):
             res = (ctrls, [v ^ 1 if c in head else v for c, v in zip(ctrls, vals)], tgt)
     if len(_SHAPES) > 4096:
@@ -321,29 +357,29 @@ def _emit_phase_block(definition, qmap, out):
     for p in ops[1::3]:
         if getattr(p, "condition", None) is not None or getattr(p, "ctrl_state", None) not in (None, 1):
             return False
-    and_keys = []
-    prev_d = prev_k = None
-    for k, o in enumerate(ops):
-        if k % 3 == 1:
-            and_keys.append(None)
-            continue
-        d = getattr(o, "definition", None)
-        if d is None or getattr(o, "condition", None) is not None:
+    # every AND is read afresh, compute and uncompute alike: QCMRF.py:225,227 builds a new object per append
+    t = n // 3
+    ands = ops[0::3] + ops[2::3]
+    try:
+        if any([o.condition for o in ands]):
             return False
-        if d is prev_d:                                     # compute / uncompute share one definition object
-            ak = prev_k
-        else:                                               # ... and so may many blocks of one circuit: read each object once per walk
-            memo = out._and_memo
-            ak = memo.get(id(d), memo)
-            if ak is memo:
-                ak = memo[id(d)] = _and_key(d)
-        if ak is None:
-            return False
-        prev_d, prev_k = d, ak
-        and_keys.append(ak)
+    except AttributeError:                                  # no .condition attribute at all (Qiskit >= 2)
+        pass
+    defs = [getattr(o, "definition", None) for o in ands]
+    if any([d is None for d in defs]):
+        return False
+    keys = [_and_key(d) for d in defs]
+    if any([k is None for k in keys]):
+        return False
+    and_keys = [None] * n
+    and_keys[0::3] = keys[:t]
+    and_keys[2::3] = keys[t:]
     qi = {id(b): i for i, b in enumerate(qs)}
-    key = (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]),
-           tuple([qi[id(q)] for qa in qargs for q in qa]), tuple(and_keys))
+    try:
+        pos = tuple([qi[id(q)] for qa in qargs for q in qa])
+    except KeyError:                                        # bits equal to, but not, the definition's own objects
+        pos = tuple([definition.find_bit(q).index for qa in qargs for q in qa])
+    key = (tuple([o.name for o in ops]), tuple([len(qa) for qa in qargs]), pos, tuple(and_keys))
     blk = _block_of_key(key)
     if blk is None:
         return False
@@ -413,15 +449,15 @@ def _walk(circuit, qmap, cmap, out, depth):
         triples = [_unpack(ci) for ci in data]
     primitives = _PRIMITIVES
     for op, qargs, cargs in triples:
-        if qi is not None:
+        try:
             q = [qmap[qi[id(b)]] for b in qargs]
-        else:
+        except (KeyError, TypeError):                        # no .qubits list, or bits that are equal to but not the circuit's own objects
             q = [qmap[_index_of(circuit, b, cache)] for b in qargs]
         name = op.name
         if getattr(op, "condition", None) is not None:
             raise ValueError("classically conditioned operation %r is not supported" % name)
         if name == "measure":
-            c = [cmap[ci_map[id(b)] if ci_map is not None else _index_of(circuit, b, cache)] for b in cargs]
+            c = [cmap[_cbit(circuit, ci_map, b, cache)] for b in cargs]
             out.measure[c[0]] = q[0]
             out._measured.add(q[0])
             out.n_source_ops += 1
@@ -448,7 +484,7 @@ def _walk(circuit, qmap, cmap, out, depth):
         if definition is not None:
             if out.peephole and (_emit_phase_block(definition, q, out) or _emit_conjugated_mcx(definition, q, out)):
                 continue
-            c = [cmap[ci_map[id(b)] if ci_map is not None else _index_of(circuit, b, cache)] for b in cargs]
+            c = [cmap[_cbit(circuit, ci_map, b, cache)] for b in cargs]
             _walk(definition, q, c, out, depth + 1)
             continue
         to_matrix = getattr(op, "to_matrix", None)
@@ -585,8 +621,13 @@ def ingest(circuit, peephole=False, keep_measures=False):
     out.keep_measures = bool(keep_measures)
     out._measured = set()
     out._phase_blocks = []
-    out._and_memo = {}               # id(definition) -> signature, for THIS walk only (the objects are alive throughout)
-    if not (peephole and not keep_measures and _walk_flat(circuit, out)):
+    flat = False
+    if peephole and not keep_measures:
+        try:
+            flat = _walk_flat(circuit, out)
+        except KeyError:                     # bits that are equal to, but not, the circuit's own objects: take the general walk
+            out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops = [], {}, set(), 0.0, 0
+    if not flat:
         _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
     _finish_phase_blocks(out)
     cregs = getattr(circuit, "cregs", None)

@@ -157,22 +157,16 @@ class QCMRF(QuantumCircuit):
             g = self.gamma[first_param + off]
             if np.isclose(g, 0):
                 continue
-            flags = tuple((np.array(y) * 2 - 1).tolist())
-            # compute and uncompute are the same gate (QCMRF.py:225,227) -- and so is every AND of the circuit with the
-            # same flags: ONE object per (size, flags), as Qiskit shares its standard-gate objects.  A reader that walks
-            # the circuit (qcmrf_amd.ingest) then meets 4 distinct definitions instead of 76 at 19 two-cliques.
-            gates = self.__dict__.setdefault("_and_gates", {})
-            conj = gates.get((len(C), flags))
-            if conj is None:
-                conj = gates[(len(C), flags)] = AND(len(C), list(flags)).to_instruction()
-            sub.append(conj, wires)
+            flags = (np.array(y) * 2 - 1).tolist()
+            # a fresh AND per append, compute and uncompute alike, exactly as QCMRF.py:225,227: the engine's
+            # ingest recognises the blocks by content, however many distinct objects spell them
+            sub.append(AND(len(C), flags), wires)
             sub.cp(2 * g, n, n + 1)
-            sub.append(conj, wires)
+            sub.append(AND(len(C), flags), wires)
         return sub
 
     def _build(self):
         n = self._n
-        self._and_gates, inverses = {}, {}
         for q in range(n):
             self.h(q)
         if self._with_barriers:
@@ -192,7 +186,7 @@ class QCMRF(QuantumCircuit):
             self.h(anc)
             self.append(cu, main + [anc])
             self.x([anc])
-            self.append(cu.inverse(_shared=inverses), main + [anc])
+            self.append(cu.inverse(), main + [anc])
             self.x([anc])
             self.h(anc)
             if self._with_measurements:

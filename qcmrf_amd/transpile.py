@@ -155,14 +155,17 @@ def _lower(circuit, qmap, cmap, em, out):
             raise ValueError("transpile: no rule for %r" % name)
 
 
-def transpile(circuits, basis_gates=None):
-    """``transpile(circuit | [circuits], basis_gates=['cx','id','rz','sx','x'])``"""
+def transpile(circuits, basis_gates=None, circuit_class=None):
+    """``transpile(circuit | [circuits], basis_gates=['cx','id','rz','sx','x'])``; the result is built through
+    the public gate methods (``rz sx x cx id measure barrier``, ``global_phase``) of ``circuit_class``
+    (default: the in-tree container; any Qiskit-style QuantumCircuit class works)"""
+    QC = circuit_class or QuantumCircuit
     if basis_gates is not None and sorted(basis_gates) != sorted(BASIS):
         raise ValueError("this stand-in lowers to %s only" % BASIS)
     single = not isinstance(circuits, (list, tuple))
     outs = []
     for c in ([circuits] if single else circuits):
-        out = QuantumCircuit(c.num_qubits, c.num_clbits, name=getattr(c, "name", "circuit"))
+        out = QC(c.num_qubits, c.num_clbits, name=getattr(c, "name", "circuit"))
         _lower(c, list(range(c.num_qubits)), list(range(c.num_clbits)), _Emitter(out), out)
         outs.append(out)
     return outs[0] if single else outs

@@ -78,10 +78,20 @@ def zsx_synthesis(U, tol=1e-12):
     return done([("rz", [lam]), ("sx", []), ("rz", [th + PI]), ("sx", []), ("rz", [ph + PI])])
 
 
+def _like(circ):
+    """an empty circuit of the input's own class (the in-tree container or the strict Qiskit double), public API only"""
+    cls = type(circ)
+    for base in cls.__mro__:                       # QCMRF(...) objects: their circuit base class
+        if base.__name__ == "QuantumCircuit":
+            cls = base
+            break
+    return cls(circ.num_qubits, circ.num_clbits, name=circ.name, global_phase=circ.global_phase)
+
+
 def merge_1q_runs(circ):
     """Optimize1qGatesDecomposition-like: re-synthesise every maximal one-qubit run per wire (only if
     the result is not longer than the run, as Qiskit does)"""
-    out = QuantumCircuit(circ.num_qubits, circ.num_clbits, name=circ.name, global_phase=circ.global_phase)
+    out = _like(circ)
     pending = {}                         # qubit -> list of (name, params)
 
     def flush(q):
@@ -148,11 +158,11 @@ def cancel_adjacent_cx(circ):
                 continue
         for q in qs:
             last[q] = i
-    out = QuantumCircuit(circ.num_qubits, circ.num_clbits, name=circ.name, global_phase=circ.global_phase)
+    out = _like(circ)
     for i, ci in enumerate(data):
         if alive[i]:
-            out._add(ci.operation, [out.qubits[circ.find_bit(b).index] for b in ci.qubits],
-                     [out.clbits[circ.find_bit(b).index] for b in ci.clbits])
+            out.append(ci.operation, [circ.find_bit(b).index for b in ci.qubits],
+                       [circ.find_bit(b).index for b in ci.clbits])
     return out
 
 

@@ -71,7 +71,15 @@ def test_top_level_instruction_sequence_matches_reference_build():
     assert [qc.find_bit(q).index for q in qc.data[5].qubits] == [0, 1, 2, 3, 4, 5]
     assert [qc.find_bit(q).index for q in qc.data[12].qubits] == [0, 1, 2, 3, 4, 6]
     andg = cu.definition.data[0].operation
-    assert [c.operation.name for c in andg.definition.data] == ["x", "x", "ccx", "x", "x"]     # y = (0,0)
+    # Qiskit's AND is a circuit holding ONE gate "and" whose definition is x.. mcx x..
+    assert [c.operation.name for c in andg.definition.data] == ["and"]
+    inner = andg.definition.data[0].operation
+    assert [c.operation.name for c in inner.definition.data] == ["x", "x", "ccx", "x", "x"]     # y = (0,0)
+    # a fresh AND per append (QCMRF.py:225,227) and per-instruction inverses (QCMRF.py:234): no object is shared
+    ands = [c.operation for ci in qc.data if ci.operation.name.startswith("cU_C") for c in ci.operation.definition.data
+            if c.operation.name.startswith("and")]
+    assert len(ands) == 3 * 2 * 8 and len(set(map(id, ands))) == len(ands)
+    assert [c.operation.name for c in qc.data[7].operation.definition.data] == ["and_dg", "cp", "and_dg"] * 4
     wb = QCMRF(C, [-0.3] * 12, with_barriers=True, with_measurements=False)
     assert [ci.operation.name for ci in wb.data].count("barrier") == 4 and "measure" not in [ci.operation.name for ci in wb.data]
 
