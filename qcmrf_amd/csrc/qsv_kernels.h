@@ -544,7 +544,9 @@ __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict_
   bool okl[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const uint64_t low = lane_off + (uint64_t)u * ustep;       // < 1024: the low address bits of this thread's u-th amplitude
+    // < 1024: the low address bits of this thread's u-th amplitude -- plus the shard number's bits below 10 when the
+    // shard is smaller than one step (L < 10: a qubit or a fix bit on a shard bit in [L, 10) lives in `hi`)
+    const uint64_t low = (lane_off + (uint64_t)u * ustep) | (hi & lowmask);
     uint32_t j = 0;
     for (int b = 0; b < q.n; ++b) if (q.pos[b] < 10) j |= (uint32_t)((low >> q.pos[b]) & 1ull) << b;
     jl[u] = j;

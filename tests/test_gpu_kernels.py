@@ -399,6 +399,35 @@ def test_expect_diag(lib, P):
         with pytest.raises(ValueError):
             e.expect_diag([1, 1], np.zeros(4))
 
+@pytest.mark.parametrize("n,P", [(10, 4), (11, 4), (9, 8), (7, 8), (11, 2)])
+def test_expect_diag_shards_smaller_than_one_step(lib, n, P):
+    """shards of fewer than 1024 amplitudes (L < 10): qubits and fix bits on the shard bits in [L, 10) come from the
+    shard number, not from the thread's low offset (they were read as 0)"""
+    ref = rand_state(n, 41)
+    p = np.abs(ref) ** 2
+    idx = np.arange(2 ** n)
+    rs = np.random.RandomState(3)
+    L = n - (P.bit_length() - 1)
+    with lib.Engine(n, devices=(0,) * P) as e:
+        e.set_amplitudes(0, ref)
+        for trial in range(12):
+            k = int(rs.randint(1, n + 1))
+            qs = [int(x) for x in rs.permutation(n)[:k]]
+            if trial < 4:                                  # every shard bit among the table's qubits
+                qs = list(range(L, n)) + [q for q in qs if q < L][:max(0, k - (n - L))]
+            tab = rs.randn(2 ** len(qs))
+            j = np.zeros_like(idx)
+            for b, q in enumerate(qs):
+                j |= ((idx >> q) & 1) << b
+            got = e.expect_diag(qs, tab)
+            assert abs(got[0] - (p * tab[j]).sum()) < 1e-13 and abs(got[1] - 1.0) < 1e-13, (trial, qs)
+            fm = int(rs.randint(0, 2 ** n)) | (1 << (n - 1)) | (1 << L)          # fix bits on shard bits and local bits
+            fv = int(rs.randint(0, 2 ** n)) & fm
+            sel = (idx & fm) == fv
+            got = e.expect_diag(qs, tab, fm, fv)
+            assert abs(got[0] - (p[sel] * tab[j[sel]]).sum()) < 1e-13 and abs(got[1] - p[sel].sum()) < 1e-13, (trial, qs, fm, fv)
+
+
 
 def test_sampling_matches_distribution(lib):
     n = 10
