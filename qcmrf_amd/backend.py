@@ -233,7 +233,7 @@ class QsvBackend:
         # every qubit of a dense window has to be local to a shard at the same time
         g = max(1, int(n_shards)).bit_length() - 1
         ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)),
-                              dense_kmax=max(1, min(5, ing.num_qubits - g)))
+                              dense_kmax=max(1, min(5, ing.num_qubits - g)), flat=ing.flat)
         if ing.global_phase and opts.get("apply_global_phase", True):
             from . import ir
             ph = np.exp(1j * ing.global_phase)

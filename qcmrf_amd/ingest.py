@@ -15,6 +15,7 @@ again, QCMRF.py:239); a circuit that does either is rejected.
 """
 from __future__ import annotations
 
+import cmath
 import re
 
 import numpy as np
@@ -33,6 +34,7 @@ class Ingested:
         self.global_phase = 0.0
         self.creg_sizes = None        # [(name, size)] in declaration order, if the circuit has cregs
         self.n_source_ops = 0
+        self.flat = None              # basis-gate circuits: what the flat walk already knows about each wire (see _walk_flat)
 
 
 def _index_of(circuit, bit, cache):
@@ -522,6 +524,13 @@ def _walk_flat(circuit, out):
     ops = out.ops
     pend, slot = {}, {}                    # wire -> [m00, m01, m10, m11]; wire -> index of its placeholder in ops
     measured = out._measured
+    # what the passes would otherwise find by walking the op list again (passes.split_leading / hoist_leading):
+    touched = set()                        # wires something has been placed on
+    leadslot = {}                          # wire -> index of the run that opens it (nothing on the wire before it)
+    role = {}                              # wire -> 'c' / 't': how its first two-qubit gate uses it
+    dense = set()                          # wires that are a dense target after their opening run (cx target, non-diagonal run)
+    hrest = {}                             # wire -> Hadamard-like gates after its opening run (a general 2x2 counts as two)
+    classify = ir.classify_1q
 
     def flush(q):
         m = pend.pop(q, None)
@@ -529,13 +538,28 @@ def _walk_flat(circuit, out):
             return
         i = slot.pop(q)
         m00, m01, m10, m11 = m
-        if m01 == 0 and m10 == 0:
-            if m00 != 1 or m11 != 1:
-                ops[i] = ir.Op("diag", qubits=(q,), table=np.array([m00, m11], dtype=np.complex128))
-        elif m00 == 0 and m11 == 0 and m01 == 1 and m10 == 1:
-            ops[i] = ir.Op("x", target=q)
-        else:
+        cls = classify(m00, m01, m10, m11)
+        if cls is None:                                   # not unitary?  keep the numbers, let the passes decide
             ops[i] = ir.Op("u", target=q, mat=np.array([[m00, m01], [m10, m11]], dtype=np.complex128), label="run")
+            dense.add(q)
+            return
+        tag = cls[0]
+        if tag == "D":
+            if abs(m00 - 1) > 1e-15 or abs(m11 - 1) > 1e-15:
+                ops[i] = ir.Op("diag", qubits=(q,), cls=cls)
+            return
+        opening = leadslot.get(q) == i
+        if not opening:
+            dense.add(q)
+        if tag == "A":
+            if abs(m01 - 1) < 1e-15 and abs(m10 - 1) < 1e-15:
+                ops[i] = ir.Op("x", target=q)
+            else:
+                ops[i] = ir.Op("u", target=q, cls=cls, label="run")
+            return
+        ops[i] = ir.Op("u", target=q, cls=cls, label="run")
+        if not opening:
+            hrest[q] = hrest.get(q, 0) + (1 if tag == "h" else 2)
 
     out.global_phase += float(getattr(circuit, "global_phase", 0.0) or 0.0)
     n_src = 0
@@ -553,6 +577,9 @@ def _walk_flat(circuit, out):
             m = pget(q)
             if m is None:
                 m = pend[q] = [1, 0, 0, 1]
+                if q not in touched:
+                    touched.add(q)
+                    leadslot[q] = len(ops)
                 slot[q] = len(ops)
                 ops.append(None)
             if name == "rz":
@@ -565,8 +592,8 @@ def _walk_flat(circuit, out):
                         raise ValueError("unbound or non-numeric parameter %r in gate 'rz'" % (lam,))
                     if len(_RZ_PHASES) > 4096:
                         _RZ_PHASES.clear()
-                    e = np.exp(0.5j * f)
-                    ph = _RZ_PHASES[lam] = (complex(e.conjugate()), complex(e))
+                    e = cmath.exp(0.5j * f)
+                    ph = _RZ_PHASES[lam] = (e.conjugate(), e)
                 e0, e1 = ph
                 m[0] *= e0
                 m[1] *= e0
@@ -590,6 +617,13 @@ def _walk_flat(circuit, out):
             n_src += 1
             flush(q)
             flush(t)
+            if q not in role:
+                role[q] = "c"
+                touched.add(q)
+            if t not in role:
+                role[t] = "t"
+                touched.add(t)
+            dense.add(t)
             ops.append(ir.Op("x", target=t, ctrls=(q,), vals=(1,)))
             continue
         if name == "measure":
@@ -606,7 +640,9 @@ def _walk_flat(circuit, out):
             n_src += 1
     for q in sorted(pend):
         flush(q)
+    lead = {q: ops[i] for q, i in leadslot.items() if ops[i] is not None}
     out.ops = [o for o in ops if o is not None]
+    out.flat = {"lead": lead, "role": role, "dense": dense, "hrest": hrest}
     out.n_source_ops += n_src
     return True
 
@@ -626,7 +662,7 @@ def ingest(circuit, peephole=False, keep_measures=False):
         try:
             flat = _walk_flat(circuit, out)
         except KeyError:                     # bits that are equal to, but not, the circuit's own objects: take the general walk
-            out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops = [], {}, set(), 0.0, 0
+            out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops, out.flat = [], {}, set(), 0.0, 0, None
     if not flat:
         _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
     _finish_phase_blocks(out)

@@ -16,6 +16,9 @@ swap     a, b                       physical layout swap (planner output only)
 """
 from __future__ import annotations
 
+import cmath
+import math
+
 import numpy as np
 
 SQ2 = 1.0 / np.sqrt(2.0)
@@ -65,22 +68,96 @@ def snap(m, tol=4e-16):
     return re + 1j * im
 
 
+def classify_1q(m00, m01, m10, m11):
+    """A unitary 2x2, entries as Python numbers, as one of (angles only, D(t) = diag(1, e^{it})):
+        ('D', g, a)            e^{ig} D(a)                         diagonal
+        ('A', g, a)            X e^{ig} D(a)                       anti-diagonal
+        ('h', g, al, be)       e^{ig} D(al) H D(be)                every entry of modulus 1/sqrt2
+        ('G', g, th, b1, a2)   e^{ig} D(a2) H D(th) H D(b1)        anything else (H D(th) H = e^{i th/2} Rx(th))
+    or None if it is not unitary to 1e-12.  Tolerances, not exact zeros: products of merged one-qubit runs carry
+    rounding residue where an exact zero belongs."""
+    a00, a01 = abs(m00), abs(m01)
+    if a01 < 1e-15 and abs(m10) < 1e-15:
+        if abs(a00 - 1.0) > 1e-12 or abs(abs(m11) - 1.0) > 1e-12:
+            return None
+        return ("D", cmath.phase(m00), cmath.phase(m11 / m00))
+    if a00 < 1e-15 and abs(m11) < 1e-15:
+        if abs(a01 - 1.0) > 1e-12 or abs(abs(m10) - 1.0) > 1e-12:
+            return None
+        return ("A", cmath.phase(m10), cmath.phase(m01 / m10))
+    if abs(a00 - SQ2) < 1e-12 and abs(a01 - SQ2) < 1e-12:
+        return ("h", cmath.phase(m00), cmath.phase(m10 / m00), cmath.phase(m01 / m00))
+    if not 1e-12 < a00 < 1.0 - 1e-13:
+        return None
+    th = 2.0 * math.acos(a00)
+    p = m00 / a00
+    js = -1j * math.sin(0.5 * th)
+    b1, a2 = cmath.phase(m01 / (p * js)), cmath.phase(m10 / (p * js))
+    if abs(m11 - p * a00 * cmath.exp(1j * (a2 + b1))) > 1e-12:
+        return None
+    return ("G", cmath.phase(p) - 0.5 * th, th, b1, a2)
+
+
+_H = None
+
+
+def _mat_of_cls(c):
+    k = c[0]
+    g = cmath.exp(1j * c[1])
+    if k == "D":
+        return np.array([[g, 0.0], [0.0, g * cmath.exp(1j * c[2])]], dtype=np.complex128)
+    if k == "A":
+        return np.array([[0.0, g * cmath.exp(1j * c[2])], [g, 0.0]], dtype=np.complex128)
+    if k == "h":
+        a, b = cmath.exp(1j * c[2]), cmath.exp(1j * c[3])
+        return (g * SQ2) * np.array([[1.0, b], [a, -a * b]], dtype=np.complex128)
+    th, b1, a2 = cmath.exp(1j * c[2]), cmath.exp(1j * c[3]), cmath.exp(1j * c[4])
+    # D(a2) H D(th) H D(b1) = 1/2 [[1 + th, (1 - th) b1], [(1 - th) a2, (1 + th) a2 b1]]
+    return (0.5 * g) * np.array([[1.0 + th, (1.0 - th) * b1], [(1.0 - th) * a2, (1.0 + th) * a2 * b1]], dtype=np.complex128)
+
+
 class Op:
-    __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "mat", "table", "mats", "angle", "mask",
-                 "a", "b", "label", "new_pass", "_sup")
+    __slots__ = ("kind", "target", "ctrls", "vals", "qubits", "_mat", "_table", "mats", "angle", "mask",
+                 "a", "b", "label", "new_pass", "_sup", "cls")
 
     def __init__(self, kind, target=None, ctrls=(), vals=(), qubits=(), mat=None, table=None, mats=None,
-                 angle=0.0, mask=0, a=(), b=(), label=""):
+                 angle=0.0, mask=0, a=(), b=(), label="", cls=None):
         self.kind = kind
         self.target = target
         self.ctrls, self.vals, self.qubits = ctrls, vals, qubits
-        self.mat, self.table, self.mats = mat, table, mats
+        self._mat, self._table, self.mats = mat, table, mats
         self.angle = angle
         self.mask = mask
         self.a, self.b = a, b
         self.label = label
         self.new_pass = False        # planner hint: this gate opens a new multi-gate pass
         self._sup = None             # cached support(); whoever re-targets a copied op resets it
+        # one-qubit gates met while walking a basis-gate circuit carry what kind of 2x2 they are as a few angles
+        # (classify_1q); the arrays are built on first use
+        self.cls = cls
+
+    @property
+    def mat(self):
+        m = self._mat
+        if m is None and self.cls is not None and self.kind == "u":
+            m = self._mat = _mat_of_cls(self.cls)
+        return m
+
+    @mat.setter
+    def mat(self, m):
+        self._mat = m
+
+    @property
+    def table(self):
+        t = self._table
+        if t is None and self.cls is not None and self.kind == "diag":
+            g = cmath.exp(1j * self.cls[1])
+            t = self._table = np.array([g, g * cmath.exp(1j * self.cls[2])], dtype=np.complex128)
+        return t
+
+    @table.setter
+    def table(self, t):
+        self._table = t
 
     def support(self):
         """every logical qubit the op reads or writes (cached: the passes ask for it constantly)"""

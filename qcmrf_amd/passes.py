@@ -1023,7 +1023,7 @@ def fuse_sandwich(ops):
 # --------------------------------------------------------------------------------------------
 # helpers for circuits lowered to a basis by a transpiler (run_experiment.py:52)
 # --------------------------------------------------------------------------------------------
-def hoist_leading(ops, split=None):
+def hoist_leading(ops, split=None, lone_h=False):
     """A transpiler emits gates in some topological order of the circuit's DAG: the one-qubit run
     that opens a wire (the lowered H of QCMRF.py:204-205, merged with whatever one-qubit gates
     follow it) may sit anywhere before the wire's first two-qubit gate, in the middle of another
@@ -1044,6 +1044,17 @@ def hoist_leading(ops, split=None):
             dense = op.dense_targets()
             starts_as_target.update(q for q in fresh if q in dense)
             seen.update(fresh)
+    if lone_h and starts_as_target:
+        # ... unless that opening gate is the ONLY non-monomial one-qubit gate the wire ever sees: then the wire is a
+        # select all the same (an MRF variable whose first two-qubit gate happens to be the cx tail of a lowered CCX,
+        # which targets a control); a scratch or ancilla wire meets a second Hadamard-like gate that closes its block
+        again = set()
+        for op in rest:
+            if op.kind == "u" and not op.ctrls and op.target in starts_as_target:
+                m = op.mat
+                if min(abs(m[0, 0]), abs(m[0, 1])) > 1e-12:
+                    again.add(op.target)
+        starts_as_target &= again
     front, keep = [], {}
     for q in sorted(lead):
         m = lead[q]
@@ -1218,9 +1229,6 @@ def absorb_x(ops):
 # --------------------------------------------------------------------------------------------
 def _fuse_body(ops, level, kmax, smax, lowered=False, dense_kmax=5):
     head, body = ops[:1], ops[1:]
-    if lowered and level >= 3:
-        # basis-gate input: re-assemble the blocks first, while the gate order is still pristine
-        body = defer_1q(fuse_dense(body, kmax=dense_kmax))
     if level >= 2:
         body = fuse_sandwich(body)
     body = fuse_monomial(body, kmax=kmax)
@@ -1231,21 +1239,96 @@ def _fuse_body(ops, level, kmax, smax, lowered=False, dense_kmax=5):
     return head + body
 
 
-def optimise(ops, level=3, kmax=10, smax=8, fresh=True, dense_kmax=5):
+def reassemble(body, dense_kmax=5):
+    """basis-gate input: re-assemble the blocks first, while the gate order is still pristine -- symbolically
+    (unlower: integer arithmetic per gate, exact); what that has to pass on as raw gates goes through the
+    numeric <= 5-qubit windows"""
+    from .unlower import unlower
+    body, n_raw = unlower(body)
+    if n_raw:
+        body = fuse_dense(body, kmax=dense_kmax)
+    return defer_1q(body)
+
+
+def merge_diagonals(ops):
+    """Diagonal gates commute with each other and with everything that is diagonal on their qubits (a multiplexer on
+    its selects): each one travels forward to the next gate that is DENSE on one of its qubits (or to the end) and
+    multiplies into a diagonal already waiting there on the same qubits or a superset of them.  What is left of the
+    phases a lowered circuit scatters over its variable wires (a T of a hoisted opening run here, its inverse out of
+    the last Toffoli network there) meets and cancels."""
+    out, pend = [], []                                   # pend: [qubits tuple, table] in arrival order
+
+    def emit(entry):
+        d = _reduce_diag(entry[0], entry[1])
+        if d is not None:
+            out.append(d)
+
+    for op in ops:
+        if op.kind in ("diag", "mcphase"):
+            q, t = _as_diag(op)
+            qs = set(q)
+            host = next((e for e in pend if qs <= set(e[0])), None)
+            if host is None:
+                grown = [e for e in pend if set(e[0]) < qs]     # the newcomer is the superset: it takes the smaller ones in
+                host = [tuple(q), np.array(t, dtype=np.complex128)]
+                for e in grown:
+                    pend.remove(e)
+                    _mul_into(host, e[0], e[1])
+                pend.append(host)
+            else:
+                _mul_into(host, q, t)
+            continue
+        dense = set(op.dense_targets())
+        if dense and pend:
+            keep = []
+            for e in pend:
+                if dense.intersection(e[0]):
+                    emit(e)
+                else:
+                    keep.append(e)
+            pend = keep
+        out.append(op)
+    for e in pend:
+        emit(e)
+    return out
+
+
+def _mul_into(host, qubits, table):
+    """host[1] *= table, the table's index bits re-read from the host's qubit order"""
+    hq = host[0]
+    j = np.arange(host[1].size)
+    k = np.zeros_like(j)
+    for e, q in enumerate(qubits):
+        k |= ((j >> hq.index(q)) & 1) << e
+    host[1] = host[1] * np.asarray(table)[k]
+
+
+def optimise(ops, level=3, kmax=10, smax=8, fresh=True, dense_kmax=5, flat=None):
     """level 0: gate by gate as ingested (|0..0> init prepended).
     level 1: + init folding + diagonal (monomial) fusion.   level 2: + multiplexer fusion.
     level 3: + dense <= 5-qubit windows with structure recovery (for basis-gate circuits)
-             + (``fresh``) gates on untouched qubits folded into the initial product state."""
-    out = _optimise(ops, level, kmax, smax, dense_kmax)
+             + (``fresh``) gates on untouched qubits folded into the initial product state.
+    ``flat``: what ingest's walk of a basis-gate circuit already knows about each wire (Ingested.flat): the run
+    that opens it, how its first two-qubit gate uses it, whether it is a dense target later -- saves three walks
+    over thousands of ops; one-qubit runs are merged already."""
+    out = _optimise(ops, level, kmax, smax, dense_kmax, flat)
     return fold_fresh(out) if (fresh and level >= 3) else out
 
 
-def _optimise(ops, level, kmax, smax, dense_kmax=5):
+def _optimise(ops, level, kmax, smax, dense_kmax=5, flat=None):
     if level <= 0:
         return [ir.op_init(0)] + list(ops)
-    lead, rest = split_leading(ops)
-    cands = set(q for q, m in lead.items() if _is_hlike(m))
-    hold0 = set(q for op in rest for q in op.dense_targets()) & cands
+    if flat is not None:
+        lead_ops = flat["lead"]
+        lead = {q: np.array(_as_1q(o)[1], dtype=np.complex128) for q, o in lead_ops.items()}
+        skip = set(map(id, lead_ops.values()))
+        rest = [o for o in ops if id(o) not in skip]
+        cands = set(q for q, m in lead.items() if _is_hlike(m))
+        hold0 = flat["dense"] & cands
+    else:
+        lead, rest = split_leading(ops)
+        cands = set(q for q, m in lead.items() if _is_hlike(m))
+        hold0 = set(q for op in rest for q in op.dense_targets()) & cands
     if level < 3 or hold0 != cands or not cands:
         return _fuse_body(fold_init(ops, hold=hold0, split=(lead, rest)), level, kmax, smax, dense_kmax=dense_kmax)
     # every candidate looks dense in the raw stream: a circuit lowered to basis gates, where even
@@ -1253,8 +1336,25 @@ def _optimise(ops, level, kmax, smax, dense_kmax=5):
     # its own target).  Re-assemble the blocks first with nothing folded; in THAT op list the
     # variable qubits' opening gates stand alone in front and are never dense again, so the
     # ordinary rule applies to it.
-    front, rest = hoist_leading(ops, split=(lead, rest))
-    fused = _fuse_body([ir.op_init(0)] + merge_1q_runs(rest), level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
-    refolded = fold_init(absorb_x(front + fused[1:]))
+    if flat is not None:
+        # hoist_leading's rule, read off the wire facts: an opening run goes to the front unless its wire starts as a
+        # TARGET and meets another Hadamard-like gate later (scratch, ancilla: the run is part of its block and sits
+        # where the run began -- right in front of the wire's first gate -- already)
+        role, hrest = flat["role"], flat["hrest"]
+        front, keep = [], set()
+        for q in sorted(lead_ops):
+            if role.get(q) == "t" and hrest.get(q, 0) > 0:
+                keep.add(id(lead_ops[q]))
+            else:
+                front.append(lead_ops[q])
+        body = [o for o in ops if id(o) not in skip or id(o) in keep]
+    else:
+        front, rest = hoist_leading(ops, split=(lead, rest), lone_h=True)
+        body = merge_1q_runs(rest)
+    # the X gates the blocks leave behind (the +-flag X of QCMRF.py:224-227, merged and re-ordered by a transpiler) go back
+    # to being control values BEFORE the multiplexer pass sees them as dense gates on the variable qubits
+    body = absorb_x(front + reassemble(body, dense_kmax))
+    fused = _fuse_body([ir.op_init(0)] + body, level, kmax, smax, lowered=True, dense_kmax=dense_kmax)
+    refolded = fold_init(fused[1:])
     refolded[0].mask |= fused[0].mask
-    return refolded
+    return refolded[:1] + merge_diagonals(refolded[1:])

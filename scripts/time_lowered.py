@@ -12,11 +12,11 @@ qc = QCMRF(C, wl.theta_halfnorm(wl.dimension(C)))
 for label, t in (("nested (as constructed)", qc), ("hand lowering", transpile(qc)), ("transpiler-shaped", lower_like_qiskit(qc))):
     N = 5
     for _ in range(2):
-        ing = I.ingest(t, peephole=True); ops = P.optimise(ing.ops, level=3, fresh=True)
+        ing = I.ingest(t, peephole=True); ops = P.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
     t0 = time.perf_counter()
     for _ in range(N): ing = I.ingest(t, peephole=True)
     t1 = time.perf_counter()
-    for _ in range(N): ops = P.optimise(ing.ops, level=3, fresh=True)
+    for _ in range(N): ops = P.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
     t2 = time.perf_counter()
     for _ in range(N):
         pl = planner.plan(ops, ing.num_qubits, 1, "auto"); program.encode(pl.ops)

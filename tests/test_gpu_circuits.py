@@ -316,11 +316,13 @@ def test_lowered_basis_gate_circuits(be, models, fusion):
     from qcmrf_amd import QCMRF
     from qcmrf_amd.transpile import transpile
     from test_host_logic import rand_circuit, oracle_state_of
-    for j in (1, 2, 4, 5):
+    for j in range(7):                                        # every graph of run_experiment.py:20, the 4-variable clique included
         C = models["0.25"]["GRAPHS"][j]
         th = models["0.25"]["THETAS"][str(j)][2]
         amp, meta = run_state(be, transpile(QCMRF(C, th)), fusion=fusion)
         assert np.abs(amp - cf.amplitudes(C, th)).max() < 5e-12
+        if fusion == 3:                                       # re-assembled completely: no dense k-qubit gate reaches the device
+            assert "kq" not in [o.kind for o in be.last_plan.ops], j
     for seed in (1, 2, 3):
         qc = rand_circuit(11, 120, 70 + seed)
         amp, meta = run_state(be, transpile(qc), fusion=fusion)

@@ -1,0 +1,112 @@
+"""CPU: symbolic re-assembly of basis-gate circuits (qcmrf_amd/unlower.py) -- what run_experiment.py:52 feeds the
+simulator.  Exactness against dense matrices on random circuits, and full re-assembly (one multiplexer per clique,
+no dense k-qubit gate left) for all seven reference graphs (run_experiment.py:20), incl. the 3- and 4-variable cliques."""
+import numpy as np
+import pytest
+
+from conftest import random_theta
+from _qiskit_shapes import lower_like_qiskit
+from oracle import closed_form as cf
+from qcmrf_amd import QCMRF, ir, passes, unlower, workloads
+from qcmrf_amd.backend import QsvBackend
+from qcmrf_amd.circuit import QuantumCircuit
+from qcmrf_amd.ingest import ingest
+from qcmrf_amd.transpile import transpile
+from test_host_logic import run_numpy
+
+
+def unitary_of(ops, n):
+    """dense 2^n x 2^n of an op list (passes._op_on_rows applies each gate to the rows of U)"""
+    U = np.eye(2 ** n, dtype=np.complex128)
+    pos = {q: q for q in range(n)}
+    for o in ops:
+        if o.kind == "init":
+            continue
+        passes._op_on_rows(U, o, pos)
+    return U
+
+
+def random_structured(n, depth, seed):
+    """gates a QCMRF-like circuit is made of, at random: h, x, rz, p, cx, ccx with +-flags, cp, mcx"""
+    rs = np.random.RandomState(seed)
+    qc = QuantumCircuit(n)
+    for _ in range(depth):
+        r = rs.randint(9)
+        q = [int(x) for x in rs.permutation(n)]
+        if r == 0:
+            qc.h(q[0])
+        elif r == 1:
+            qc.x(q[0])
+        elif r == 2:
+            qc.rz(float(rs.uniform(-3, 3)), q[0])
+        elif r == 3:
+            qc.p(float(rs.uniform(-3, 3)), q[0])
+        elif r == 4:
+            qc.cx(q[0], q[1])
+        elif r == 5:
+            qc.ccx(q[0], q[1], q[2])
+        elif r == 6:
+            qc.cp(float(rs.uniform(-3, 3)), q[0], q[1])
+        elif r == 7 and n >= 4:
+            qc.mcx(q[:3], q[3])
+        else:                                     # H . (monomial) . H: the shape unlower closes as a multiplexer
+            qc.h(q[0]); qc.cp(float(rs.uniform(-3, 3)), q[1], q[0]); qc.cx(q[2], q[0]); qc.rz(0.3, q[0]); qc.h(q[0])
+    return qc
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_unlower_is_exact_on_random_basis_gate_circuits(seed):
+    n = 4 + seed % 3
+    qc = random_structured(n, 30, 100 + seed)
+    for t in (transpile(qc), lower_like_qiskit(qc), lower_like_qiskit(qc, merge=False)):
+        ing = ingest(t, peephole=True)
+        out, n_raw = unlower.unlower(ing.ops)
+        want = unitary_of(ing.ops, n)
+        got = unitary_of(out, n)
+        assert np.abs(got - want).max() < 1e-11, (seed, n_raw)
+        # and through the whole pass pipeline, sharded or not
+        ref = unitary_of(ingest(t).ops, n)[:, 0] * np.exp(1j * ingest(t).global_phase)
+        for shards in (1, 2):
+            amp, _, _, _ = run_numpy(t, fusion=3, shards=shards)
+            assert np.abs(amp - ref).max() < 1e-11
+
+
+def test_every_reference_graph_comes_back_as_one_multiplexer_per_clique():
+    """run_experiment.py:20: all seven graphs, hand-lowered and transpiler-shaped: no dense gate is left, every clique
+    block is ONE multiplexer (fold_fresh off) / one factor of the initial state (default)"""
+    be = QsvBackend()
+    for j, C in enumerate(workloads.REFERENCE_GRAPHS):
+        th = random_theta(workloads.dimension(C), seed=j)
+        qc = QCMRF(C, th)
+        n, m, W, dim = cf.model_shape(C)
+        for t in (transpile(qc), lower_like_qiskit(qc)):
+            ing, pl = be.compile(t, fold_fresh=False)
+            kinds = [o.kind for o in pl.ops]
+            assert kinds.count("mux") == m and "kq" not in kinds and set(kinds) <= {"init", "mux", "diag"}, (j, kinds)
+            ing, pl = be.compile(t)
+            kinds = [o.kind for o in pl.ops]
+            assert set(kinds) <= {"init", "diag"} and bin(pl.ops[0].mask).count("1") == n + m, (j, kinds)
+            amp, _, _, _ = run_numpy(t, fusion=3)
+            assert np.abs(amp - cf.amplitudes(C, th)).max() < 2e-12, j
+
+
+def test_config5_lowered_compiles_to_the_generator_form():
+    """BASELINE configs[4] lowered (7.4 k gates): init + 19 diagonal factors + a global phase, nothing parked"""
+    name, C = workloads.baseline_config(4)
+    t = transpile(QCMRF(C, workloads.theta_halfnorm(workloads.dimension(C))))
+    ing = ingest(t, peephole=True)
+    assert ing.flat is not None and len(ing.ops) < len(t.data)
+    ops = passes.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
+    kinds = [o.kind for o in ops]
+    assert kinds[0] == "init" and kinds.count("diag") <= 21 and set(kinds) == {"init", "diag"}
+
+
+def test_unlower_passes_on_what_it_cannot_hold():
+    """a non-unitary 'u', a 3-qubit diagonal, a bracket that never closes: emitted as they came, result still exact"""
+    rs = np.random.RandomState(5)
+    q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
+    ops = [ir.op_u(0, ir.FIXED_1Q["h"]), ir.op_x(1, [0]), ir.op_diag([0, 1, 2], np.exp(1j * rs.randn(8))), ir.op_u(1, q),
+           ir.op_x(2, [1]), ir.op_u(0, 2.0 * ir.FIXED_1Q["h"]), ir.op_x(0, [2]), ir.op_u(2, ir.FIXED_1Q["h"])]
+    out, n_raw = unlower.unlower(ops)
+    assert n_raw >= 1
+    assert np.abs(unitary_of(out, 3) - unitary_of(ops, 3)).max() < 1e-12
