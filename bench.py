@@ -238,8 +238,8 @@ def timed_leg(backend, comm, qc, shots, steps, warmup, seed0=1984, options=(), *
     backend.last_engine.sync()
     comm.barrier()
     elapsed = max(comm.allgather(time.perf_counter() - t0))
-    counts = res.get_counts()
-    assert sum(counts.values()) == shots
+    counts = res.get_counts()                   # the merged dict on rank 0; empty on the other ranks (backend: gather_counts="root")
+    assert sum(counts.values()) == (shots if comm.rank == 0 else 0), (comm.rank, sum(counts.values()))
     dom = max(agg, key=lambda k: agg[k]["ms"])
     d = agg[dom]
     return {"elapsed": elapsed, "meta": meta, "agg": agg, "dom": dom, "counts": counts,
@@ -372,7 +372,8 @@ def exchange_legs_in_child_processes(args, rank):
     child's JSON from a pipe; a child that outlives the deadline is killed."""
     import subprocess
     env = dict(os.environ)
-    env["QSV_COMM_ENDPOINT"] = "unix:qsv-bench-legs-%s-%s" % (env.get("MASTER_ADDR", "127.0.0.1"), env.get("MASTER_PORT", "29500"))
+    from qcmrf_amd import comm as qcomm
+    env["QSV_COMM_ENDPOINT"] = qcomm.child_endpoint(env, "bench-legs")     # unix socket on one node, TCP across nodes: the parent's own rule
     cmd = [sys.executable, os.path.abspath(__file__), "--exchange-child", "--gpus", str(args.gpus), "--shots", str(args.shots),
            "--fusion", str(args.fusion), "--exchange-deadline", str(args.exchange_deadline)]
     if args.qubits:
@@ -431,13 +432,16 @@ def main():
         if rank == 0:
             print(json.dumps(legs), flush=True)
         sys.stdout.flush()
-        os._exit(0)                       # a transport may still sit in a device call on some rank
+        bad = bool(legs.get("abandoned")) or any(isinstance(v, dict) and "error" in v for v in legs.values())
+        os._exit(1 if bad else 0)         # (_exit: a transport may still sit in a device call on some rank)
     backend = QsvBackend(fusion=args.fusion, layout=args.layout, comm=comm if world > 1 else None,
                          device=device, devices=(0,) * max(1, args.virtual_shards), fold_fresh=not args.no_fold)
 
     main_leg = timed_leg(backend, comm, qc, args.shots, args.steps, args.warmup, options=args.option)
     elapsed, meta, agg = main_leg["elapsed"], main_leg["meta"], main_leg["agg"]
     validation = validate_last_step(backend, comm, qc, cliques, theta, main_leg["counts"], args.shots)
+    # host time per rank (what does not shrink with the rank count): compile + sample/merge/format of the timed steps
+    host_by_rank = comm.allgather({k: round(v, 4) for k, v in main_leg["breakdown_ms"].items()}) if world > 1 else None
 
     # untimed-for-`value` extra legs (every rank takes part; reported under "variants")
     variants = {}
@@ -498,6 +502,51 @@ def main():
             assert len(rb.get_counts()) == nb
             variants["batch of %d circuits in one run() call (host compile overlapped with device work)" % nb] = {
                 "shots_per_s": args.shots * nb / dt, "ms_per_step": dt / nb * 1e3}
+
+    # the "next" rows of SURVEY.md 8(f), measured by this run (N = 1): the diagonal-observable read pass on the resident
+    # 34-qubit state (f4: qsv_expect_diag) and trajectory mode beyond statevector reach (f3)
+    expect_roof = None
+    if world == 1 and not args.no_variants:
+        eng = backend.last_engine
+        if backend.last_plan is None or len(backend.last_plan.layout) != W:
+            backend.run(qc, shots=0)
+            eng = backend.last_engine
+        n_var = qc.num_vertices
+        hdiag = qc.hamiltonian_diagonal()
+        fixed = {q: 0 for q in range(n_var, W)}
+        backend.expectation_diagonal(hdiag, list(range(n_var)), fixed)
+        eng.sync()
+        reps = 5
+        eng.timer_begin()
+        for _ in range(reps):
+            backend.expectation_diagonal(hdiag, list(range(n_var)), fixed)
+        ms = eng.timer_end() / reps
+        nbytes = 16.0 * 2.0 ** W
+        expect_roof = {"bound": "hbm", "kernel": "k_expect_diag (<H> of QCMRF.Hamiltonian() post-selected on all ancillas 0: one read pass, %d-entry table)" % hdiag.size,
+                       "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+                       "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches": reps,
+                       "note": "HIP events around qsv_expect_diag calls (kernel + the partial-sum read-back)"}
+        try:
+            from qcmrf_amd.backend import QsvBackend as _QB
+            tC = wl.chain(22)                                   # 22 variables, 21 cliques: a 44-qubit circuit, 24 live qubits
+            tq = QCMRF(tC, wl.theta_halfnorm(wl.dimension(tC), scale=0.25))
+            backend.close()                                     # (the 256 GiB state leaves the device first)
+            tb = _QB(method="trajectory", fusion=args.fusion)
+            tb.run(tq, shots=256, seed_simulator=1)             # warm-up: engine creation, kernels
+            t0 = time.perf_counter()
+            tr = tb.run(tq, shots=args.shots, seed_simulator=2).result()
+            dt = time.perf_counter() - t0
+            tm = tr.metadata(0)
+            assert sum(tr.get_counts().values()) == args.shots
+            variants["trajectory mode (mid-circuit measurements taken as they occur, QCMRF.py:238-239): 22-variable chain MRF, "
+                     "W = 44 circuit qubits"] = {
+                "shots_per_s": args.shots / dt, "ms_per_step": dt * 1e3, "circuit_qubits": tq.num_qubits,
+                "live_qubits": tm.get("live_qubits"), "segments": tm.get("n_segments"),
+                "branch_nodes": tm.get("branch_nodes"), "state_copies": tm.get("state_copies"), "device_ops": tm.get("device_ops"),
+                "shots": args.shots}
+            tb.close()
+        except Exception as e:                                   # noqa: BLE001
+            variants["trajectory mode W = 44"] = {"error": repr(e)[:300]}
 
     # N = 1: the other single-GPU configs of BASELINE.json, same step definition (not part of `value`)
     other = {}
@@ -585,6 +634,7 @@ def main():
                        "parallelism": "amplitude shards by high qubit x%d" % (args.virtual_shards or args.gpus)
                                       + (" (virtual shards on one device)" if args.virtual_shards else "")},
             "breakdown_ms": main_leg["breakdown_ms"],
+            "breakdown_ms_by_rank": host_by_rank,
             "kernels": main_leg["kernels"],
             "roofline": roof,
             "validation": validation,
@@ -601,6 +651,8 @@ def main():
                     "avg_launch_ms": km["avg_ms"], "launches_per_step": km["launches_per_step"],
                     "shots_per_s": v["shots_per_s"], "ms_per_step": v["ms_per_step"],
                     "note": "variant, not part of `value`: fold_fresh=False"}
+        if expect_roof:
+            line["roofline_expect_diag"] = expect_roof
         if sweeps28:
             line["roofline_gate_sweeps_28q"] = sweeps28
         if gates28:
@@ -618,6 +670,8 @@ def main():
     if world > 1:
         comm.barrier()
         comm.close()
+    if rank == 0 and not validation["ok"]:
+        sys.exit("bench.py: the state the timed steps left in HBM failed validation (see \"validation\" in the line above)")
 
 
 if __name__ == "__main__":

@@ -107,13 +107,15 @@ class QsvBackend:
                 'trajectory' (mid-circuit measurements taken when they occur, measured qubits
                 released: n+2 live qubits for a QCMRF circuit, see qcmrf_amd.trajectory)
     comm        process group for one-process-per-GPU launches (qcmrf_amd.comm)
+    gather_counts  'root' (default: rank 0 returns the merged counts, the other ranks an empty dict) | 'all' 
     device      HIP device of this rank when ``comm`` is given
     """
 
     def __init__(self, name="qasm_simulator", **options):
         self._name = name
         self.options = {"fusion": 3, "layout": "auto", "devices": (0,), "comm": None, "device": 0,
-                        "profile": False, "engine_options": None, "method": "statevector", "fold_fresh": True}
+                        "profile": False, "engine_options": None, "method": "statevector", "fold_fresh": True,
+                        "gather_counts": "root"}
         self.options.update(options)
         self._engine = None
         self._engine_key = None
@@ -318,12 +320,14 @@ class QsvBackend:
         counts = {}
         if clist and shots > 0:
             if comm.world > 1:
-                # Two tiny collectives per run: (1) one double per rank, the shard's probability
-                # mass -> the common multinomial split of the shots over the shards (same seed on
-                # every rank); (2) each rank draws exactly split[rank] outcomes from its own shard
-                # and ships them as (distinct outcome, count) pairs.  Measured against shipping
-                # `shots` draws from every rank in one collective: 8 B + a few hundred pairs per
-                # rank instead of 32 KiB, and each rank samples and sorts 1/P of the shots.
+                # One round trip and one one-way send per run: (1) all-gather of one double per rank, the shard's
+                # probability mass -> the common multinomial split of the shots over the shards (same seed on every
+                # rank); (2) each rank draws exactly split[rank] outcomes from its own shard and SENDS them to rank 0
+                # as (distinct outcome, count) pairs -- a few hundred pairs -- without waiting for anything back.
+                # Only rank 0 merges and formats: Result.get_counts() is the merged dict there and empty on the
+                # other ranks (metadata "counts_on_rank": 0), whose step ends with the send -- formatting 4096 keys on
+                # every rank was host time that does not shrink with the rank count (``gather_counts="all"``
+                # restores the all-gather: every rank then returns the full dict).
                 masses = np.asarray(comm.allgather_f64(eng.norm()) if hasattr(comm, "allgather_f64")
                                     else comm.allgather(eng.norm()), dtype=np.float64)
                 split = np.random.RandomState(seed % (2 ** 32)).multinomial(shots, masses / masses.sum())
@@ -331,16 +335,19 @@ class QsvBackend:
                 mine = eng.sample(k, (seed * 1315423911 + comm.rank) % (2 ** 63), meas_phys) if k else np.zeros(0, dtype=np.uint64)
                 uv, uc = np.unique(self._to_clbits(mine, clist, direct), return_counts=True)
                 pairs = np.concatenate([uv, uc.astype(np.uint64)])
-                if hasattr(comm, "allgather_bytes"):
-                    parts = [np.frombuffer(b, dtype=np.uint64) for b in comm.allgather_bytes(pairs.tobytes())]
+                everyone = opts.get("gather_counts", "root") == "all"
+                if everyone or not hasattr(comm, "gather_bytes"):
+                    raw = comm.allgather_bytes(pairs.tobytes()) if hasattr(comm, "allgather_bytes") else [np.asarray(b, dtype=np.uint64).tobytes() for b in comm.allgather(pairs)]
                 else:
-                    parts = [np.asarray(b, dtype=np.uint64) for b in comm.allgather(pairs)]
-                av = np.concatenate([b[:b.size // 2] for b in parts])
-                ac = np.concatenate([b[b.size // 2:] for b in parts]).astype(np.int64)
-                # shards that differ only in an unmeasured qubit can produce the same outcome
-                uv, inv = np.unique(av, return_inverse=True)
-                uc = np.bincount(inv, weights=ac, minlength=uv.size).astype(np.int64) if uv.size != av.size else ac[np.argsort(av, kind="stable")]
-                counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
+                    raw = comm.gather_bytes(pairs.tobytes())
+                if raw is not None:
+                    parts = [np.frombuffer(b, dtype=np.uint64) for b in raw]
+                    av = np.concatenate([b[:b.size // 2] for b in parts])
+                    ac = np.concatenate([b[b.size // 2:] for b in parts]).astype(np.int64)
+                    # shards that differ only in an unmeasured qubit can produce the same outcome
+                    uv, inv = np.unique(av, return_inverse=True)
+                    uc = np.bincount(inv, weights=ac, minlength=uv.size).astype(np.int64) if uv.size != av.size else ac[np.argsort(av, kind="stable")]
+                    counts = _format_keys(uv, uc, ing.num_clbits, ing.creg_sizes)
             else:
                 vals = self._to_clbits(eng.sample(shots, seed, meas_phys), clist, direct)
                 uv, uc = np.unique(vals, return_counts=True)
@@ -352,6 +359,8 @@ class QsvBackend:
                 "n_exchanges": pl.n_exchanges, "n_shards": n_shards, "layout": list(pl.layout),
                 "fusion": opts["fusion"], "time_compile": t1 - t0, "time_evolve": t2 - t1,
                 "time_sample": t3 - t2, "time_taken": t3 - t0, "seed_simulator": seed}
+        if comm.world > 1 and opts.get("gather_counts", "root") != "all":
+            meta["counts_on_rank"] = 0
         if opts["profile"]:
             meta["stats"] = eng.stats()
             eng.set_profiling(False)

@@ -766,6 +766,126 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
 }
 
 // ---------------------------------------------------------------------------------------
+// k_kq_mfma3<K>: the same contraction with THREE real matrix products per complex one (Gauss):
+//     t1 = (Ur + Ui) x Br      t2 = Ur x (Bi - Br)      t3 = Ui x (Br + Bi)
+//     D_re = t1 - t3           D_im = t1 + t2
+// At K = 5 the four-product form needs 64 v_mfma_f64_16x16x4_f64 per 16 KiB of traffic -- 0.8 of the
+// f64 matrix peak at 8 TB/s, which is what bounded it (kq5: 0.59-0.68 of the stream) -- this one 48.
+// The combined A fragments (Ur + Ui) are made once per kernel; the two extra operands cost two
+// VALU adds per loaded amplitude, the recombination two per stored one.  PF: the next batch's
+// amplitudes are requested before the current batch's MFMAs start (two waves per SIMD at K = 5
+// do not hide a load behind 48 MFMAs by themselves).
+// ---------------------------------------------------------------------------------------
+template <int K, bool NT, bool PF>
+__global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, uint64_t nbatch,
+                                                      BitIns ins, KqOffs offs,
+                                                      const double* __restrict__ ur,
+                                                      const double* __restrict__ ui, int chunked) {
+  constexpr int D = 1 << K, MB = D / 16, KS = D / 4;
+  const int lane = threadIdx.x & 63;
+  const int jcol = lane & 15, kq = lane >> 4;
+  double as[MB][KS], ar[MB][KS], ai[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
+      ar[mb][ks] = ur[i * D + k];
+      ai[mb][ks] = ui[i * D + k];
+      as[mb][ks] = ar[mb][ks] + ai[mb][ks];
+    }
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (QSV_TPB / 64) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (QSV_TPB / 64);
+  const uint64_t per = (nbatch + nwaves - 1) / nwaves;
+  const uint64_t bt0 = chunked ? wave0 * per : wave0, bt1 = chunked ? (bt0 + per < nbatch ? bt0 + per : nbatch) : nbatch;
+  const uint64_t bstep = chunked ? 1 : nwaves;
+  cplx v[KS];
+  uint64_t base = 0;
+  if (bt0 < bt1) {
+    base = ins_bits(bt0 * 16 + jcol, ins);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | offs.off[ks * 4 + kq])) : amp[base | offs.off[ks * 4 + kq]];
+  }
+  for (uint64_t bt = bt0; bt < bt1; bt += bstep) {
+    cplx vn[KS];
+    uint64_t nbase = 0;
+    const bool more = bt + bstep < bt1;
+    if (PF && more) {
+      nbase = ins_bits((bt + bstep) * 16 + jcol, ins);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) vn[ks] = NT ? ld_nt(amp + (nbase | offs.off[ks * 4 + kq])) : amp[nbase | offs.off[ks * 4 + kq]];
+    }
+    f64x4 t1[MB], t2[MB], t3[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      t1[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      t2[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      t3[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const double bre = v[ks].x, dif = v[ks].y - v[ks].x, sum = v[ks].x + v[ks].y;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mb][ks], bre, t1[mb], 0, 0, 0);
+        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[mb][ks], dif, t2[mb], 0, 0, 0);
+        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[mb][ks], sum, t3[mb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const cplx o = make_double2(t1[mb][r] - t3[mb][r], t1[mb][r] + t2[mb][r]);
+        if (NT) st_nt(amp + (base | offs.off[mb * 16 + kq + 4 * r]), o);
+        else amp[base | offs.off[mb * 16 + kq + 4 * r]] = o;
+      }
+    if (PF) {
+      base = nbase;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) v[ks] = vn[ks];
+    } else if (more) {
+      base = ins_bits((bt + bstep) * 16 + jcol, ins);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | offs.off[ks * 4 + kq])) : amp[base | offs.off[ks * 4 + kq]];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_kq_tile<K>: dense 2^K x 2^K (K <= 3) on the vector units, one thread per group of 2^K amplitudes
+// in registers, one group per thread and no grid-stride loop (the stream shape of every other sweep here),
+// matrix rows read from LDS as broadcasts.  8 * 2^K flop per 32 B is 2 flop/B at K = 3: a quarter of
+// what the f64 vector units deliver at 8 TB/s, so the pass is the HBM stream it looks like; embedded
+// in a 16 x 16 matrix-core tile as I (x) U it paid for twice the products and ran at 0.64.
+// ---------------------------------------------------------------------------------------
+template <int K, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_kq_tile(cplx* __restrict__ amp, uint64_t ngroups,
+                                                     BitIns ins, KqOffs offs,
+                                                     const cplx* __restrict__ umat, int swz) {
+  constexpr int D = 1 << K;
+  extern __shared__ double4 lds_raw[];
+  cplx* lu = reinterpret_cast<cplx*>(lds_raw);
+  for (int i = threadIdx.x; i < D * D; i += QSV_TPB) lu[i] = umat[i];
+  __syncthreads();
+  const uint64_t g = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x;
+  if (g >= ngroups) return;
+  uint64_t base = ins_bits(g, ins);
+  if (swz) base = swz_5_11(base);                          // no target on bit 5 or 11 (host)
+  cplx in[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) in[c] = NT ? ld_nt(amp + (base | offs.off[c])) : amp[base | offs.off[c]];
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    cplx acc = cmul(lu[r * D], in[0]);
+#pragma unroll
+    for (int c = 1; c < D; ++c) acc = cmad(lu[r * D + c], in[c], acc);
+    if (NT) st_nt(amp + (base | offs.off[r]), acc);
+    else amp[base | offs.off[r]] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // tuning variant of the dense pair kernel (selected by option "pair_variant"): separate
 // non-temporal hints for loads / stores, deeper unroll, and an XCD-aware block remap (blocks are
 // dealt round-robin over the 8 XCDs; the remap gives every XCD one contiguous eighth of the pairs)

@@ -142,6 +142,30 @@ def test_kq_dense(lib, n, k, mfma):
         assert np.abs(e.amplitudes() - ref).max() < 1e-12
 
 
+@pytest.mark.parametrize("variant,tile3,nt,chunked", [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 1, 0, 0), (1, 1, 1, 0), (2, 0, 1, 1),
+                                                    (2, 1, 1, 0)])
+@pytest.mark.parametrize("n,k", [(9, 3), (14, 3), (12, 4), (13, 5), (16, 5)])
+def test_kq_kernel_variants(lib, n, k, variant, tile3, nt, chunked):
+    """every form of the dense k-qubit gate: four real matrix-core products per complex one (0), three (Gauss, 1), three
+    with the next batch prefetched (2, default); K = 3 on the vector units (k_kq_tile, default) or embedded in a 16 x 16
+    matrix-core tile; plain and non-temporal / index-swizzled access; grid-stride and contiguous walks -- against numpy"""
+    rs = np.random.RandomState(n * 31 + k)
+    ref = rand_state(n, 23)
+    with lib.Engine(n) as e:
+        e.set_option("kq_variant", variant)
+        e.set_option("kq3_tile", tile3)
+        e.set_option("nontemporal", nt)
+        e.set_option("swizzle", 2 if nt else 1)
+        e.set_option("kq_chunked", chunked)
+        e.set_amplitudes(0, ref)
+        for trial in range(5):
+            qs = rs.permutation(n)[:k].tolist() if trial else list(range(k))       # incl. the k lowest bits
+            u = rand_u(k, 40 + trial)
+            e.apply_kq(qs, u)
+            sv.apply_kq(ref, qs, u)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-12
+
+
 def test_nontemporal_kernel_forms(lib):
     """every one-gate kernel in its non-temporal form (loads and stores that bypass the caches: what
     states of >= 2^26 amplitudes select by themselves) against the numpy oracle at a size where the

@@ -103,3 +103,75 @@ def test_socket_comm_collectives_in_threads():
         assert o["u64"].shape == (world, 4) and o["u64"][3].tolist() == [30, 31, 32, 33]
         assert o["f64"].tolist() == [0.0, 0.5, 1.0, 1.5, 2.0]
         assert o["bytes"] == [bytes([i]) * i for i in range(world)]
+
+
+def test_socket_comm_gather_and_data_only_frames():
+    """gather_bytes: only the hub receives (the tail of the sampling merge); frames carry data, never pickles: an object
+    the codec does not know is refused on the sending side, an unknown tag on the receiving side"""
+    import threading
+    import numpy as np
+    from qcmrf_amd import comm as qc
+    world, port = 3, free_port()
+    res, errs = {}, []
+
+    def body(r):
+        try:
+            env = {"RANK": str(r), "WORLD_SIZE": str(world), "QSV_COMM_ENDPOINT": "tcp:127.0.0.1:%d" % port}
+            c = qc.SocketComm(timeout_s=60, env=env)
+            res[r] = (c.gather_bytes(bytes([65 + r]) * (r + 1)), c.allgather(np.arange(3) * (1 + 1j) * r))
+            c.barrier()
+            c.close()
+        except Exception as e:                                    # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(60) for t in th]
+    assert not errs, errs
+    assert res[0][0] == [b"A", b"BB", b"CCC"] and res[1][0] is None and res[2][0] is None
+    assert all(np.array_equal(res[r][1][2], np.arange(3) * (2 + 2j)) for r in range(world))
+    with pytest.raises(TypeError):
+        qc.encode({"f": open})                                    # a callable is not data
+    with pytest.raises(TypeError):
+        qc.encode(np.array([object()]))
+    import pickle
+    with pytest.raises(ValueError):
+        qc.decode(pickle.dumps({"a": 1}))                         # a pickle is not a frame of this codec
+    assert "pickle" not in open(qc.__file__).read().replace("never pickle", "").replace("unpickled", "").replace("pickles", "")
+
+
+def test_socket_comm_refuses_a_peer_without_the_launch_key():
+    """the hello carries a MAC under a key derived from the launcher's environment (or QSV_COMM_TOKEN): a process that
+    merely reaches the rendezvous address is turned away"""
+    import threading
+    from qcmrf_amd.comm import SocketComm
+    port = free_port()
+    out = {}
+
+    def hub():
+        try:
+            SocketComm(timeout_s=10, env={"RANK": "0", "WORLD_SIZE": "2", "QSV_COMM_ENDPOINT": "tcp:127.0.0.1:%d" % port,
+                                          "QSV_COMM_TOKEN": "right"})
+            out["hub"] = "accepted"
+        except ConnectionError as e:
+            out["hub"] = str(e)
+
+    def intruder():
+        try:
+            SocketComm(timeout_s=10, env={"RANK": "1", "WORLD_SIZE": "2", "QSV_COMM_ENDPOINT": "tcp:127.0.0.1:%d" % port,
+                                          "QSV_COMM_TOKEN": "wrong"})
+            out["peer"] = "accepted"
+        except Exception as e:                                    # noqa: BLE001
+            out["peer"] = repr(e)
+    th = [threading.Thread(target=hub), threading.Thread(target=intruder)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    assert "not a rank of this launch" in out["hub"] and out["peer"] != "accepted", out
+
+
+def test_child_endpoint_follows_the_parent_rule():
+    from qcmrf_amd.comm import child_endpoint
+    one = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511", "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8"}
+    assert child_endpoint(one, "legs").startswith("unix:") and child_endpoint(one, "legs").endswith("-legs")
+    two = dict(one, WORLD_SIZE="16", MASTER_ADDR="node0")
+    assert child_endpoint(two, "legs") == "tcp:node0:29513"
+    assert child_endpoint(dict(one, QSV_COMM_ENDPOINT="unix:whatever"), "legs") == child_endpoint(one, "legs")
