@@ -181,7 +181,11 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = -1;                    // one-gate sweeps non-temporal: -1 by shard size and bit positions (single_nt), 0 never, 1 always
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
-  int opt_kq_variant = 2;             // k_kq_mfma: 0 four real products per complex one, 1 three (Gauss), 2 three + the next batch prefetched
+  int opt_kq_variant = 3;             // k_kq_mfma: 0 four real products per complex one, 1 three (Gauss), 2 three + the next batch prefetched, 3 = 2 with the A fragments in LDS (default), 4 = 1 with them in LDS
+  int opt_general_combos = 1;         // general k_multi passes: controls on workgroup-uniform bits resolved per workgroup (combo table)
+  int opt_fold_init_h = 1;            // qsv_exec: H on a still-|0> qubit right after an init is part of the init write
+  int exec_ops_left = 1 << 30;            // qsv_exec: ops of the running program not yet consumed (group_fits lets the tail ride along)
+  int opt_kq_blocks_per_cu = 0;       // k_kq_mfma grid: workgroups per CU (0: 64)
   int opt_kq3_tile = 1;               // dense 3-qubit gates on the vector units (k_kq_tile) instead of I (x) U on a 16 x 16 matrix-core tile
   int opt_kq_chunked = 0;             // k_kq_mfma: every wave walks a contiguous run of batches instead of a grid-stride loop (experiment)
   int opt_blocksum_variant = 6;       // access pattern of the read-only passes (qsv_measure.inc): 2 wave-contiguous, 4 no grid-stride loop, 1 index swizzle

@@ -776,7 +776,9 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma(cplx* __restrict__ amp, uin
 // amplitudes are requested before the current batch's MFMAs start (two waves per SIMD at K = 5
 // do not hide a load behind 48 MFMAs by themselves).
 // ---------------------------------------------------------------------------------------
-template <int K, bool NT, bool PF>
+// ALDS: the three A fragments of every 16 x 4 slice live in LDS (24 KiB per workgroup at K = 5, one 8-byte read per
+// lane and MFMA) instead of 96 VGPRs: three waves per SIMD instead of two.
+template <int K, bool NT, bool PF, bool ALDS = false>
 __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, uint64_t nbatch,
                                                       BitIns ins, KqOffs offs,
                                                       const double* __restrict__ ur,
@@ -784,16 +786,34 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
   constexpr int D = 1 << K, MB = D / 16, KS = D / 4;
   const int lane = threadIdx.x & 63;
   const int jcol = lane & 15, kq = lane >> 4;
-  double as[MB][KS], ar[MB][KS], ai[MB][KS];
+  extern __shared__ double lds_a[];                        // ALDS: [mb][ks][3][64 lanes]
+  double as[ALDS ? 1 : MB][ALDS ? 1 : KS], ar[ALDS ? 1 : MB][ALDS ? 1 : KS], ai[ALDS ? 1 : MB][ALDS ? 1 : KS];
+  if constexpr (ALDS) {
+    if (threadIdx.x < 64) {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
-      ar[mb][ks] = ur[i * D + k];
-      ai[mb][ks] = ui[i * D + k];
-      as[mb][ks] = ar[mb][ks] + ai[mb][ks];
+        for (int ks = 0; ks < KS; ++ks) {
+          const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
+          const double r = ur[i * D + k], m = ui[i * D + k];
+          double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lane;
+          p[0] = r + m; p[64] = r; p[128] = m;
+        }
     }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
+        ar[mb][ks] = ur[i * D + k];
+        ai[mb][ks] = ui[i * D + k];
+        as[mb][ks] = ar[mb][ks] + ai[mb][ks];
+      }
+  }
+  // off[t] is linear in the bits of t: the lane only contributes t's two low bits (kq); the rest is uniform (scalar registers)
+  const uint64_t okq = offs.off[kq];
   const uint64_t wave0 = (uint64_t)blockIdx.x * (QSV_TPB / 64) + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * (QSV_TPB / 64);
   const uint64_t per = (nbatch + nwaves - 1) / nwaves;
@@ -804,7 +824,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
   if (bt0 < bt1) {
     base = ins_bits(bt0 * 16 + jcol, ins);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | offs.off[ks * 4 + kq])) : amp[base | offs.off[ks * 4 + kq]];
+    for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | okq | offs.off[ks * 4])) : amp[base | okq | offs.off[ks * 4]];
   }
   for (uint64_t bt = bt0; bt < bt1; bt += bstep) {
     cplx vn[KS];
@@ -813,8 +833,10 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
     if (PF && more) {
       nbase = ins_bits((bt + bstep) * 16 + jcol, ins);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) vn[ks] = NT ? ld_nt(amp + (nbase | offs.off[ks * 4 + kq])) : amp[nbase | offs.off[ks * 4 + kq]];
+      for (int ks = 0; ks < KS; ++ks) vn[ks] = NT ? ld_nt(amp + (nbase | okq | offs.off[ks * 4])) : amp[nbase | okq | offs.off[ks * 4]];
     }
+    int lofs = lane;
+    if constexpr (ALDS) asm volatile("" : "+v"(lofs));        // re-read the fragments every batch: hoisted out of the loop they are 96 VGPRs again
     f64x4 t1[MB], t2[MB], t3[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -827,18 +849,26 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
       const double bre = v[ks].x, dif = v[ks].y - v[ks].x, sum = v[ks].x + v[ks].y;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mb][ks], bre, t1[mb], 0, 0, 0);
-        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[mb][ks], dif, t2[mb], 0, 0, 0);
-        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[mb][ks], sum, t3[mb], 0, 0, 0);
+        double fs, fr, fi;
+        if constexpr (ALDS) {
+          const double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lofs;             // lofs: this batch's opaque copy of the lane id (below)
+          fs = p[0]; fr = p[64]; fi = p[128];
+        } else {
+          fs = as[mb][ks]; fr = ar[mb][ks]; fi = ai[mb][ks];
+        }
+        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fs, bre, t1[mb], 0, 0, 0);
+        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, dif, t2[mb], 0, 0, 0);
+        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, sum, t3[mb], 0, 0, 0);
       }
+      if constexpr (ALDS) __builtin_amdgcn_sched_barrier(0);   // the next slice's fragment reads stay behind this slice's MFMAs
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const cplx o = make_double2(t1[mb][r] - t3[mb][r], t1[mb][r] + t2[mb][r]);
-        if (NT) st_nt(amp + (base | offs.off[mb * 16 + kq + 4 * r]), o);
-        else amp[base | offs.off[mb * 16 + kq + 4 * r]] = o;
+        if (NT) st_nt(amp + (base | okq | offs.off[mb * 16 + 4 * r]), o);
+        else amp[base | okq | offs.off[mb * 16 + 4 * r]] = o;
       }
     if (PF) {
       base = nbase;
@@ -847,7 +877,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
     } else if (more) {
       base = ins_bits((bt + bstep) * 16 + jcol, ins);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | offs.off[ks * 4 + kq])) : amp[base | offs.off[ks * 4 + kq]];
+      for (int ks = 0; ks < KS; ++ks) v[ks] = NT ? ld_nt(amp + (base | okq | offs.off[ks * 4])) : amp[base | okq | offs.off[ks * 4]];
     }
   }
 }

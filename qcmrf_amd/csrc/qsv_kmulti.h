@@ -379,6 +379,10 @@ __device__ __forceinline__ void gen_op(cplx (&a)[1 << R], const MultiOp& op, uin
 // runtime loop over rounds -- no branch on the target bit or around an update, so plain expressions
 // already update every amplitude in place.
 struct MultiSlot { int first; int ndiag; int has; int pad; };   // list slot: ops[first .. first+ndiag); gate slot: ops[first] if has
+// combo table of a general pass, as ints in the `slots` buffer: [0] number of combo bits nb (0: none, walk the flat list),
+// [1..8] their address positions, [9] stride of a list, then 2^nb lists of `stride` ints: count, op indices in program order
+#define QSV_COMBO_HDR 12
+#define QSV_COMBO_MAXBITS 8
 
 template <int R, int B, int MODE>
 __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __restrict__ ops,
@@ -502,9 +506,24 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     }
   }
   if constexpr (MODE == 0) {
-    // general pass: `ops` is a flat list in program order, `nrounds` its length
-    const int nops = (!INIT || live) ? nrounds : 0;
-    for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[i], base, lt);
+    // general pass: `ops` is a flat list in program order, `nrounds` its length.  `slots` carries the host's
+    // COMBO TABLE (GenCombos): the controls that sit on workgroup-uniform address bits are resolved per workgroup --
+    // for every value of (up to 8 of) those bits the host lists the ops that can fire at all, in program order, and a
+    // workgroup walks only its own list.  A CCX of the reference's stream whose two controls select workgroups is then
+    // neither loaded nor tested by the three quarters of the machine it does not concern.
+    const int* ch = reinterpret_cast<const int*>(slots);
+    const int nb = __builtin_amdgcn_readfirstlane(ch[0]);
+    if (nb == 0) {
+      const int nops = (!INIT || live) ? nrounds : 0;
+      for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[i], base, lt);
+    } else {
+      uint32_t ci = 0;
+      for (int e = 0; e < nb; ++e) ci |= (uint32_t)((base_blk >> ch[1 + e]) & 1ull) << e;
+      ci = __builtin_amdgcn_readfirstlane(ci);
+      const int* lst = ch + QSV_COMBO_HDR + (size_t)ci * (size_t)ch[9];
+      const int nops = (!INIT || live) ? lst[0] : 0;
+      for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[lst[1 + i]], base, lt);
+    }
   } else {
     constexpr int NS = R + 1;
     const int nr = (!INIT || live) ? nrounds : 0;

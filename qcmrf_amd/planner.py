@@ -181,16 +181,31 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
     free_x = sum(1 for op in ops if op.kind == "x" and len(op.ctrls) == 0)
     if lane_targets and L >= 12 and 2 * len(masked) > len(ops) - free_x:
         heat = {q: 0 for q in rest}
+        touched = set()
         for op in ops:
             if op.kind in ("u", "mux", "kq") or (op.kind == "x" and len(op.ctrls) > 0):
+                # (the one-qubit gate that opens a wire -- the H on every variable, QCMRF.py:204-205 -- is part of the init
+                # write in libqsv, qsv_exec: it does not make its qubit a target)
+                opening = op.kind == "u" and not op.ctrls and op.target not in touched
                 for q in op.dense_targets():
-                    if q in heat:
+                    if q in heat and not opening:
                         heat[q] += 1
+            touched.update(op.support())
         zeros = set(quiet_z)
-        cold = sorted((q for q in rest if q not in zeros), key=lambda q: (heat[q], 0 if (uniform >> q) & 1 else 1, q))
-        lanes = cold[:LANE_BITS]
-        above = sorted((q for q in rest if q not in zeros and q not in lanes), key=lambda q: (-heat[q], dense_first.get(q, never), q))
-        order = lanes + above + quiet_z
+        # Qubits that are ONLY ever controls (the MRF variables in the reference's stream) go to the top of the shard: up
+        # there a control selects whole workgroups, and libqsv resolves such controls per workgroup (the combo table of a
+        # general pass: a CCX is not even looked at by the three quarters of the machine it cannot fire in).  On a lane
+        # bit the same control only masks lanes -- every wave pays the op in full.  The lane bits go to the coldest qubits
+        # that are targets at all (ancillas: two masked 2x2 each, the latest-used first), then to pure controls if any
+        # lane is left.
+        live = [q for q in rest if q not in zeros]
+        pure_ctrl = [q for q in live if heat[q] == 0]
+        tgt = [q for q in live if heat[q] > 0]
+        by_cold = sorted(tgt, key=lambda q: (heat[q], -dense_first.get(q, never), q))
+        lanes = by_cold[:LANE_BITS]
+        lanes += pure_ctrl[:LANE_BITS - len(lanes)]
+        above = sorted((q for q in tgt if q not in lanes), key=lambda q: (-heat[q], dense_first.get(q, never), q))
+        order = lanes + above + [q for q in pure_ctrl if q not in lanes] + quiet_z
         pass_heads = []
     lay = [0] * n_qubits
     for p, q in enumerate(order):

@@ -574,6 +574,12 @@ def test_gate_by_gate_programs_keep_masked_targets_off_the_lane_bits():
         assert ccx and all(o.target >= 6 for o in ccx), W
         # the AND scratch qubit, target of every CCX, sits right above the lanes
         assert len({o.target for o in ccx}) == 1 and ccx[0].target <= 8
+        # the pure controls (the MRF variables) select whole workgroups: they sit on the highest bits below the scratch
+        # qubit's known-zero... i.e. above every target qubit; the lane bits carry ancillas (two dense gates each)
+        n = qc.num_vertices
+        var_pos = sorted(pl.layout[q] for q in range(n))
+        tgt_pos = sorted(pl.layout[q] for q in range(n, qc.num_qubits))
+        assert var_pos[0] > tgt_pos[-1] and tgt_pos[:6] == [0, 1, 2, 3, 4, 5], (W, var_pos, tgt_pos)
         # a permutation of the qubits, whatever the policy
         assert sorted(pl.layout) == list(range(qc.num_qubits))
         ing3, pl3 = QsvBackend().compile(qc, fusion=3)
