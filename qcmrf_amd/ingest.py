@@ -16,6 +16,7 @@ again, QCMRF.py:239); a circuit that does either is rejected.
 from __future__ import annotations
 
 import cmath
+import math
 import re
 
 import numpy as np
@@ -499,17 +500,28 @@ def _walk(circuit, qmap, cmap, out, depth):
 
 
 _FLAT_NAMES = frozenset(("rz", "sx", "x", "cx", "id", "measure", "barrier", "delay"))
-_SX = ir.FIXED_1Q["sx"]
-_SX00, _SX01 = complex(_SX[0, 0]), complex(_SX[0, 1])
-_RZ_PHASES = {}
+_PI = math.pi
+_TWO_PI = 2.0 * math.pi
+_HALF_PI = 0.5 * math.pi
+_QUARTER_PI = 0.25 * math.pi
+
+
+def _wrap(a):
+    return a - _TWO_PI * round(a / _TWO_PI)
 
 
 def _walk_flat(circuit, out):
     """A circuit already lowered to the reference's basis {cx, id, rz, sx, x} (run_experiment.py:52) is
-    thousands of one-qubit gates between CX gates.  They are multiplied into ONE 2x2 per run while
-    walking -- four complex numbers per wire, plain Python arithmetic -- and the run is emitted where it
-    BEGINS (right behind the previous gate on its wire): 5.7-7.4 k instructions of the 34-qubit circuit
-    become ~3 k ops without ever existing as 7 k objects.  Exact; used at fusion >= 1 only (fusion 0
+    thousands of one-qubit gates between CX gates.  Every maximal run of them on a wire is kept as what it IS
+    while walking -- a global phase, an X flag and the phase angles between its Hadamards,
+
+        e^{ig} X^f D(a_n) H D(a_{n-1}) H ... H D(a_0),      D(t) = diag(1, e^{it}),
+
+    so that ``rz`` is one float addition, ``x`` a flag (or a pi on the angle behind the last H) and ``sx`` =
+    e^{i pi/4} D(-pi/2) H D(-pi/2) appends an angle; H D(0) H = 1 and H D(pi) H = X fold on the spot.  The run is emitted
+    where it BEGINS (right behind the previous gate on its wire) as ONE op that carries its angles (ir.classify_1q
+    forms: 'D', 'A', 'h', 'G'; matrices are built only if somebody asks): 5.7-7.4 k instructions of the 34-qubit
+    circuit become ~3 k ops without a single complex multiplication.  Exact; used at fusion >= 1 only (fusion 0
     promises the stream gate by gate).  Returns False (nothing emitted) if the circuit is not flat."""
     data = circuit.data
     try:
@@ -522,7 +534,7 @@ def _walk_flat(circuit, out):
     if qi is None:
         return False
     ops = out.ops
-    pend, slot = {}, {}                    # wire -> [m00, m01, m10, m11]; wire -> index of its placeholder in ops
+    pend, slot = {}, {}                    # wire -> [g, f, a_0, a_1, ...]; wire -> index of its placeholder in ops
     measured = out._measured
     # what the passes would otherwise find by walking the op list again (passes.split_leading / hoist_leading):
     touched = set()                        # wires something has been placed on
@@ -530,36 +542,58 @@ def _walk_flat(circuit, out):
     role = {}                              # wire -> 'c' / 't': how its first two-qubit gate uses it
     dense = set()                          # wires that are a dense target after their opening run (cx target, non-diagonal run)
     hrest = {}                             # wire -> Hadamard-like gates after its opening run (a general 2x2 counts as two)
-    classify = ir.classify_1q
+    gph = 0.0
 
     def flush(q):
-        m = pend.pop(q, None)
-        if m is None:
+        nonlocal gph
+        st = pend.pop(q, None)
+        if st is None:
             return
         i = slot.pop(q)
-        m00, m01, m10, m11 = m
-        cls = classify(m00, m01, m10, m11)
-        if cls is None:                                   # not unitary?  keep the numbers, let the passes decide
-            ops[i] = ir.Op("u", target=q, mat=np.array([[m00, m01], [m10, m11]], dtype=np.complex128), label="run")
-            dense.add(q)
-            return
-        tag = cls[0]
-        if tag == "D":
-            if abs(m00 - 1) > 1e-15 or abs(m11 - 1) > 1e-15:
-                ops[i] = ir.Op("diag", qubits=(q,), cls=cls)
+        g, f = st[0], st[1]
+        nh = len(st) - 3
+        if nh == 0:
+            a = _wrap(st[2])
+            if f:
+                if i != leadslot.get(q):
+                    dense.add(q)
+                if abs(a) < 1e-15:
+                    gph += g
+                    ops[i] = ir.Op("x", target=q)
+                else:
+                    ops[i] = ir.Op("u", target=q, cls=("A", _wrap(g), a), label="run")
+            elif abs(a) < 1e-15:
+                gph += g                   # the run multiplied out to a number
+            else:
+                ops[i] = ir.Op("diag", qubits=(q,), cls=("D", _wrap(g), a))
             return
         opening = leadslot.get(q) == i
         if not opening:
             dense.add(q)
-        if tag == "A":
-            if abs(m01 - 1) < 1e-15 and abs(m10 - 1) < 1e-15:
-                ops[i] = ir.Op("x", target=q)
-            else:
-                ops[i] = ir.Op("u", target=q, cls=cls, label="run")
-            return
+        if nh == 1:
+            a1, a0 = st[3], st[2]
+            cls = ("h", _wrap(g + a1), _wrap(-a1), _wrap(a0 + _PI)) if f else ("h", _wrap(g), _wrap(a1), _wrap(a0))
+        elif nh == 2:
+            a2, a1, a0 = st[4], st[3], st[2]
+            cls = ("G", _wrap(g + a2), _wrap(a1 + _PI), _wrap(a0), _wrap(-a2)) if f else ("G", _wrap(g), _wrap(a1), _wrap(a0), _wrap(a2))
+        else:
+            # three or more Hadamards left in one run (generic angles between them): multiply it out after all
+            m = np.array([[1.0, 0.0], [0.0, cmath.exp(1j * st[2])]], dtype=np.complex128)
+            for a in st[3:]:
+                m = np.array([[1.0, 0.0], [0.0, cmath.exp(1j * a)]]) @ ir.FIXED_1Q["h"] @ m
+            if f:
+                m = m[::-1, :]
+            m = cmath.exp(1j * g) * m
+            cls = ir.classify_1q(complex(m[0, 0]), complex(m[0, 1]), complex(m[1, 0]), complex(m[1, 1]))
+            if cls is None:
+                ops[i] = ir.Op("u", target=q, mat=np.ascontiguousarray(m), label="run")
+                return
+            if cls[0] in ("D", "A"):       # (cannot happen for three honest Hadamards, but stay exact)
+                ops[i] = ir.Op("diag", qubits=(q,), cls=cls) if cls[0] == "D" else ir.Op("u", target=q, cls=cls, label="run")
+                return
         ops[i] = ir.Op("u", target=q, cls=cls, label="run")
         if not opening:
-            hrest[q] = hrest.get(q, 0) + (1 if tag == "h" else 2)
+            hrest[q] = hrest.get(q, 0) + (1 if cls[0] == "h" else 2)
 
     out.global_phase += float(getattr(circuit, "global_phase", 0.0) or 0.0)
     n_src = 0
@@ -574,9 +608,9 @@ def _walk_flat(circuit, out):
                 raise ValueError("gate %r acts on qubit %d after it was measured; mid-circuit measurement "
                                  "with later use of the qubit is not supported" % (name, q))
             n_src += 1
-            m = pget(q)
-            if m is None:
-                m = pend[q] = [1, 0, 0, 1]
+            st = pget(q)
+            if st is None:
+                st = pend[q] = [0.0, 0, 0.0]
                 if q not in touched:
                     touched.add(q)
                     leadslot[q] = len(ops)
@@ -584,29 +618,45 @@ def _walk_flat(circuit, out):
                 ops.append(None)
             if name == "rz":
                 lam = ci.operation.params[0]
-                ph = _RZ_PHASES.get(lam)
-                if ph is None:
+                if type(lam) is not float:
                     try:
-                        f = float(lam)
+                        lam = float(lam)
                     except TypeError:
                         raise ValueError("unbound or non-numeric parameter %r in gate 'rz'" % (lam,))
-                    if len(_RZ_PHASES) > 4096:
-                        _RZ_PHASES.clear()
-                    e = cmath.exp(0.5j * f)
-                    ph = _RZ_PHASES[lam] = (e.conjugate(), e)
-                e0, e1 = ph
-                m[0] *= e0
-                m[1] *= e0
-                m[2] *= e1
-                m[3] *= e1
-            elif name == "sx":
-                a, b, c, d = m
-                m[0] = _SX00 * a + _SX01 * c
-                m[1] = _SX00 * b + _SX01 * d
-                m[2] = _SX01 * a + _SX00 * c
-                m[3] = _SX01 * b + _SX00 * d
-            else:                                        # x: rows swapped
-                m[0], m[1], m[2], m[3] = m[2], m[3], m[0], m[1]
+                # rz(lam) = e^{-i lam/2} D(lam);  D(lam) X = e^{i lam} X D(-lam)
+                if st[1]:
+                    st[-1] -= lam
+                    st[0] += 0.5 * lam
+                else:
+                    st[-1] += lam
+                    st[0] -= 0.5 * lam
+            elif name == "x":
+                st[1] ^= 1
+            else:
+                # sx = e^{i pi/4} D(-pi/2) H D(-pi/2);  with an X in front of the run:  H X = D(pi) H
+                if st[1]:
+                    st[1] = 0
+                    st[-1] += _HALF_PI
+                    st[0] -= _QUARTER_PI
+                    new = _HALF_PI
+                else:
+                    st[-1] -= _HALF_PI
+                    st[0] += _QUARTER_PI
+                    new = -_HALF_PI
+                if len(st) > 3:
+                    mid = st[-1]
+                    mid -= _TWO_PI * round(mid / _TWO_PI)
+                    if -1e-13 < mid < 1e-13:                 # H D(0) H = 1
+                        st.pop()
+                        st[-1] += new
+                        continue
+                    if abs(abs(mid) - _PI) < 1e-13:          # H D(pi) H = X;  D(new) X = e^{i new} X D(-new)
+                        st.pop()
+                        st[-1] -= new
+                        st[0] += new
+                        st[1] = 1
+                        continue
+                st.append(new)
             continue
         if name == "cx":
             qs = ci.qubits
@@ -615,8 +665,10 @@ def _walk_flat(circuit, out):
                 raise ValueError("gate 'cx' acts on qubit %d after it was measured; mid-circuit measurement "
                                  "with later use of the qubit is not supported" % (q if q in measured else t))
             n_src += 1
-            flush(q)
-            flush(t)
+            if q in pend:
+                flush(q)
+            if t in pend:
+                flush(t)
             if q not in role:
                 role[q] = "c"
                 touched.add(q)
@@ -640,6 +692,7 @@ def _walk_flat(circuit, out):
             n_src += 1
     for q in sorted(pend):
         flush(q)
+    out.global_phase += gph
     lead = {q: ops[i] for q, i in leadslot.items() if ops[i] is not None}
     out.ops = [o for o in ops if o is not None]
     out.flat = {"lead": lead, "role": role, "dense": dense, "hrest": hrest}

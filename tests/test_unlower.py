@@ -110,3 +110,42 @@ def test_unlower_passes_on_what_it_cannot_hold():
     out, n_raw = unlower.unlower(ops)
     assert n_raw >= 1
     assert np.abs(unitary_of(out, 3) - unitary_of(ops, 3)).max() < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_flat_ingest_run_algebra_matches_matrix_products(seed):
+    """ingest._walk_flat keeps a run of rz / sx / x as angles between Hadamards (no complex arithmetic): the op it emits,
+    materialised, times the global phase it books, equals the product of the gate matrices -- for random runs incl. the
+    folds H D(0) H = 1, H D(pi) H = X, runs that multiply out to a number, and runs that keep three Hadamards"""
+    rs = np.random.RandomState(seed)
+    SX = 0.5 * np.array([[1 + 1j, 1 - 1j], [1 - 1j, 1 + 1j]])
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    special = [0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, 2 * np.pi]
+    for trial in range(60):
+        qc = QuantumCircuit(2)
+        U = np.eye(2, dtype=complex)
+        for _ in range(int(rs.randint(1, 9))):
+            r = rs.randint(4)
+            if r == 0:
+                lam = float(special[rs.randint(len(special))] if rs.rand() < 0.6 else rs.uniform(-4, 4))
+                qc.rz(lam, 0)
+                U = np.diag([np.exp(-0.5j * lam), np.exp(0.5j * lam)]) @ U
+            elif r == 1:
+                qc.sx(0)
+                U = SX @ U
+            elif r == 2:
+                qc.x(0)
+                U = X @ U
+            else:
+                qc.id(0)
+        qc.cx(0, 1)                                   # closes the run
+        ing = ingest(qc, peephole=True)
+        assert ing.flat is not None
+        run = [o for o in ing.ops if not (o.kind == "x" and o.ctrls)]
+        assert len(run) <= 1
+        got = np.eye(2, dtype=complex)
+        if run:
+            o = run[0]
+            got = X if o.kind == "x" else np.diag(o.table) if o.kind == "diag" else o.mat
+        got = np.exp(1j * ing.global_phase) * got
+        assert np.abs(got - U).max() < 1e-12, (seed, trial, [ci.operation.name for ci in qc.data])
