@@ -206,6 +206,7 @@ class QsvBackend:
             # helper thread while the device evolves and samples circuit i (ctypes releases the GIL
             # inside the blocking library calls)
             from concurrent.futures import ThreadPoolExecutor
+            opts = dict(opts, _batch=True)          # (the helper thread must not talk on the process group's socket: no SPMD ingest here)
             with ThreadPoolExecutor(max_workers=1) as pool:
                 nxt = pool.submit(self._prepare, circs[0], opts)
                 for i in range(len(circs)):
@@ -223,7 +224,8 @@ class QsvBackend:
         t0 = time.perf_counter()
         comm = opts["comm"] or SingleProcess()
         n_shards = comm.world if comm.world > 1 else len(opts["devices"])
-        ing, pl = self.compile(circuit, n_shards, **{k: opts[k] for k in ("fusion", "layout", "engine_options", "fold_fresh")})
+        ing, pl = self.compile(circuit, n_shards, ingest_comm=comm if (comm.world > 1 and opts.get("spmd_ingest", True) and not opts.get("_batch")) else None,
+                               **{k: opts[k] for k in ("fusion", "layout", "engine_options", "fold_fresh")})
         rec, data = program.encode(pl.ops)
         return ing, pl, rec, data, n_shards, time.perf_counter() - t0
 
@@ -231,7 +233,7 @@ class QsvBackend:
         """ingest + passes + plan only (no GPU): returns (Ingested, Plan)"""
         opts = dict(self.options)
         opts.update(options)
-        ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1)
+        ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1, comm=opts.get("ingest_comm"))
         # every qubit of a dense window has to be local to a shard at the same time
         g = max(1, int(n_shards)).bit_length() - 1
         ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)),

@@ -485,6 +485,23 @@ def _walk(circuit, qmap, cmap, out, depth):
             continue
         definition = getattr(op, "definition", None)
         if definition is not None:
+            if out._part is not None and depth == 0 and out.peephole:
+                # one process per GPU: the composite blocks of the top level are read by ONE rank each (round robin) and
+                # exchanged afterwards (ingest: _exchange_blocks) -- reading them is most of the compile time, and every
+                # rank reading all of them is host time that does not shrink with the rank count
+                blk = out._nblk
+                out._nblk += 1
+                if blk % out._part[1] != out._part[0]:
+                    ph = ir.Op("diag", qubits=(), table=None)
+                    out.ops.append(ph)
+                    out._remote[blk] = ph
+                    continue
+                n0, s0 = len(out.ops), out.n_source_ops
+                if _emit_phase_block(definition, q, out) and len(out.ops) == n0 + 1:
+                    out._mine.append((blk, out.ops[-1], out.n_source_ops - s0))
+                    continue
+                out._bail = True                          # not a block that comes back as one table: everyone reads everything
+                return
             if out.peephole and (_emit_phase_block(definition, q, out) or _emit_conjugated_mcx(definition, q, out)):
                 continue
             c = [cmap[_cbit(circuit, ci_map, b, cache)] for b in cargs]
@@ -700,9 +717,11 @@ def _walk_flat(circuit, out):
     return True
 
 
-def ingest(circuit, peephole=False, keep_measures=False):
+def ingest(circuit, peephole=False, keep_measures=False, comm=None):
     """peephole=True additionally folds X..X . MCX . X..X definitions (Qiskit's AND with negative
-    flags) into one MCX with negated controls while walking -- exact, and 5x fewer ops to fuse."""
+    flags) into one MCX with negated controls while walking -- exact, and 5x fewer ops to fuse.
+    comm (a process group of world > 1, every rank calling with the same circuit): the composite top-level blocks are
+    read by one rank each and exchanged in ONE all-gather; the result is the same Ingested on every rank."""
     nq = int(circuit.num_qubits)
     nc = int(getattr(circuit, "num_clbits", 0))
     out = Ingested(nq, nc)
@@ -710,6 +729,8 @@ def ingest(circuit, peephole=False, keep_measures=False):
     out.keep_measures = bool(keep_measures)
     out._measured = set()
     out._phase_blocks = []
+    out._part = (comm.rank, comm.world) if (comm is not None and comm.world > 1 and peephole and not keep_measures) else None
+    out._nblk, out._remote, out._mine, out._bail, out._exchanged = 0, {}, [], False, False
     flat = False
     if peephole and not keep_measures:
         try:
@@ -717,13 +738,44 @@ def ingest(circuit, peephole=False, keep_measures=False):
         except KeyError:                     # bits that are equal to, but not, the circuit's own objects: take the general walk
             out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops, out.flat = [], {}, set(), 0.0, 0, None
     if not flat:
-        _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
+        try:
+            _walk(circuit, list(range(nq)), list(range(nc)), out, 0)
+        except Exception:
+            if out._part is None or out._exchanged:
+                raise
+            out._bail = True                 # the others are waiting in the exchange: tell them, then fail here as a single process would
     _finish_phase_blocks(out)
+    if out._part is not None and not _exchange_blocks(out, comm):
+        return ingest(circuit, peephole=peephole, keep_measures=keep_measures)     # some block was no phase block: read it all here
     cregs = getattr(circuit, "cregs", None)
     if cregs:
         out.creg_sizes = [(getattr(r, "name", "c"), len(r)) for r in cregs]
     del out._measured
     return out
+
+
+def _exchange_blocks(out, comm):
+    """every rank contributes the blocks it read -- (index, qubits, table, source-gate count) -- and fills in the ones the
+    others read; False if any rank met a block it could not turn into one table (then nobody uses the exchange)"""
+    mine = [] if out._bail else [[blk, list(op.qubits), np.ascontiguousarray(op.table), int(n_src)] for blk, op, n_src in out._mine]
+    out._exchanged = True
+    parts = comm.allgather([bool(out._bail), mine])
+    if any(p[0] for p in parts):
+        return False
+    got = {}
+    for p in parts:
+        for blk, qubits, table, n_src in p[1]:
+            got[blk] = (qubits, table, n_src)
+    mine_ids = {blk for blk, _, _ in out._mine}
+    for blk, ph in out._remote.items():
+        if blk not in got:
+            return False
+        qubits, table, n_src = got[blk]
+        if out.measure and set(out.measure.values()).intersection(qubits):
+            return False                                   # let the local walk raise the precise error
+        ph.qubits, ph.table, ph._sup = tuple(int(x) for x in qubits), table, None
+        out.n_source_ops += n_src
+    return len(got) == len(mine_ids) + len(out._remote)
 
 
 def _finish_phase_blocks(out):

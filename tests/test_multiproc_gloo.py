@@ -175,3 +175,53 @@ def test_child_endpoint_follows_the_parent_rule():
     two = dict(one, WORLD_SIZE="16", MASTER_ADDR="node0")
     assert child_endpoint(two, "legs") == "tcp:node0:29513"
     assert child_endpoint(dict(one, QSV_COMM_ENDPOINT="unix:whatever"), "legs") == child_endpoint(one, "legs")
+
+
+def test_spmd_ingest_gives_every_rank_the_same_program():
+    """one process per GPU: each rank reads 1/world of the composite blocks of a QCMRF circuit and ONE all-gather completes
+    the picture -- identical ops (tables bit for bit) on every rank; a circuit whose blocks are not phase blocks, and one
+    that raises, fall back to everyone reading everything without leaving a rank behind in the collective"""
+    import threading
+    import numpy as np
+    from qcmrf_amd import QCMRF, workloads as wl
+    from qcmrf_amd.circuit import QuantumCircuit
+    from qcmrf_amd.comm import SocketComm
+    from qcmrf_amd.ingest import ingest
+    C = wl.grid(2, 4)
+    qc = QCMRF(C, wl.theta_halfnorm(wl.dimension(C)))
+    odd = QuantumCircuit(4, 4)                                   # a composite block that is NOT AND . cp . AND triples
+    sub = QuantumCircuit(3, name="blk")
+    sub.h(0); sub.cx(0, 1); sub.rz(0.3, 2)
+    odd.h(3); odd.append(sub, [0, 1, 2]); odd.append(sub.inverse(), [1, 2, 3]); odd.measure(0, 0)
+    bad = QuantumCircuit(3, 3)
+    bad.append(sub, [0, 1, 2]); bad.measure(0, 0); bad.append(sub, [0, 1, 2])       # gate after measurement: ValueError
+    refs = [ingest(c, peephole=True) for c in (qc, odd)]
+    world, port = 3, free_port()
+    res, errs = {}, []
+
+    def body(r):
+        try:
+            c = SocketComm(timeout_s=60, env={"RANK": str(r), "WORLD_SIZE": str(world), "QSV_COMM_ENDPOINT": "tcp:127.0.0.1:%d" % port})
+            out = [ingest(x, peephole=True, comm=c) for x in (qc, odd)]
+            try:
+                ingest(bad, peephole=True, comm=c)
+                out.append("no error")
+            except ValueError as e:
+                out.append(str(e))
+            c.barrier()
+            c.close()
+            res[r] = out
+        except Exception as e:                                    # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs and len(res) == world, errs
+    for r in range(world):
+        for got, ref in zip(res[r][:2], refs):
+            assert len(got.ops) == len(ref.ops) and got.n_source_ops == ref.n_source_ops and got.measure == ref.measure
+            for a, b in zip(got.ops, ref.ops):
+                assert a.kind == b.kind and a.support() == b.support()
+                if a.kind == "diag":
+                    assert np.array_equal(a.table, b.table)
+        assert "after it was measured" in res[r][2]
