@@ -59,6 +59,43 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64
 }
 
 // ---------------------------------------------------------------------------------------
+// k_pair_m: the same sweep when a control sits INSIDE a 128-byte line (address bits 0..2).  Enumerating only the
+// control-satisfied pairs there makes every wave instruction a row of 16-byte pieces of lines it then half uses
+// (ccx with a control on bit 1: 0.31 of the stream, 4x the charged bytes).  Here such controls are a MASK: the
+// sweep enumerates the pairs that satisfy the controls on bits >= 3, reads and writes their lines whole, and
+// applies the gate where (index & lmask) == lval.  Traffic = the lines the gate touches at all.
+// ---------------------------------------------------------------------------------------
+template <int KIND, int U, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_pair_m(cplx* __restrict__ amp, uint64_t npairs,
+                                                    BitIns ins, uint64_t fixed, uint64_t tbit,
+                                                    Mat2 m, uint64_t lmask, uint64_t lval) {
+  const cplx m00 = make_double2(m.v[0], m.v[1]), m01 = make_double2(m.v[2], m.v[3]);
+  const cplx m10 = make_double2(m.v[4], m.v[5]), m11 = make_double2(m.v[6], m.v[7]);
+  const uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x;      // npairs % (QSV_TPB * U) == 0 (host)
+  uint64_t i0[U];
+  cplx a0[U], a1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    i0[u] = ins_bits(base + (uint64_t)u * QSV_TPB, ins) | fixed;
+    a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
+    a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool on = (i0[u] & lmask) == lval;
+    cplx r0, r1;
+    if (KIND == 1) { r0 = a1[u]; r1 = a0[u]; }
+    else {
+      r0 = cmad(m01, a1[u], cmul(m00, a0[u]));
+      r1 = cmad(m11, a1[u], cmul(m10, a0[u]));
+    }
+    if (!on) { r0 = a0[u]; r1 = a1[u]; }
+    if (NT) { st_nt(amp + i0[u], r0); st_nt(amp + (i0[u] | tbit), r1); }
+    else    { st(amp + i0[u], r0);    st(amp + (i0[u] | tbit), r1); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // uncontrolled dense 2x2 on a LOW target bit (t < 6): the partner amplitude sits in another
 // lane of the same wavefront.  Each lane streams its own amplitudes (fully coalesced 1 KiB
 // per wave instruction) and fetches the partner with a wave shuffle (lane ^ (1<<t)).

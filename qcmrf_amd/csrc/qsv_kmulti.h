@@ -339,6 +339,14 @@ __device__ __forceinline__ void gen_list(cplx (&a)[1 << R], const MultiOp& op, i
   }
 }
 
+// a wave-uniform 64-bit value, in scalar registers (readfirstlane returns a SIGNED int: widen through uint32_t, or a low
+// half with bit 31 set smears ones over the high half)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+
 // One op of a general pass.  The ops come as a flat list in program order: no rounds, no empty slots.
 template <int R>
 __device__ __forceinline__ void gen_op(cplx (&a)[1 << R], const MultiOp& op, uint64_t base, const cplx* __restrict__ lt) {
@@ -380,9 +388,11 @@ __device__ __forceinline__ void gen_op(cplx (&a)[1 << R], const MultiOp& op, uin
 // already update every amplitude in place.
 struct MultiSlot { int first; int ndiag; int has; int pad; };   // list slot: ops[first .. first+ndiag); gate slot: ops[first] if has
 // combo table of a general pass, as ints in the `slots` buffer: [0] number of combo bits nb (0: none, walk the flat list),
-// [1..8] their address positions, [9] stride of a list, then 2^nb lists of `stride` ints: count, op indices in program order
+// [1..8] their address positions, then (HDR ints in, 8-byte aligned) 2^nb entries of QSV_COMBO_WORDS 64-bit masks over the
+// flat op list: bit i set <=> op i can fire in the workgroups whose combo bits spell this entry's index
 #define QSV_COMBO_HDR 12
 #define QSV_COMBO_MAXBITS 8
+#define QSV_COMBO_WORDS 2
 
 template <int R, int B, int MODE>
 __device__ __forceinline__ void multi_slot(cplx (&a)[1 << R], const MultiOp* __restrict__ ops,
@@ -513,16 +523,23 @@ __global__ __launch_bounds__(QSV_TPB, (R == 5 && MODE ? 2 : 1)) void k_multi(cpl
     // neither loaded nor tested by the three quarters of the machine it does not concern.
     const int* ch = reinterpret_cast<const int*>(slots);
     const int nb = __builtin_amdgcn_readfirstlane(ch[0]);
-    if (nb == 0) {
-      const int nops = (!INIT || live) ? nrounds : 0;
-      for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[i], base, lt);
-    } else {
-      uint32_t ci = 0;
-      for (int e = 0; e < nb; ++e) ci |= (uint32_t)((base_blk >> ch[1 + e]) & 1ull) << e;
-      ci = __builtin_amdgcn_readfirstlane(ci);
-      const int* lst = ch + QSV_COMBO_HDR + (size_t)ci * (size_t)ch[9];
-      const int nops = (!INIT || live) ? lst[0] : 0;
-      for (int i = 0; i < nops; ++i) gen_op<R>(a, ops[lst[1 + i]], base, lt);
+    uint32_t ci = 0;
+    for (int e = 0; e < nb; ++e) ci |= (uint32_t)((base_blk >> ch[1 + e]) & 1ull) << e;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+    // this workgroup's ops as a bit mask over the flat list (QSV_COMBO_WORDS x 64 ops; nb = 0: one entry, every op): the
+    // next op's index comes out of a register, so its descriptor load does not wait for an index load first.  ONE loop:
+    // the interpreter body (gen_op) exists once in the kernel.
+    const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(ch + QSV_COMBO_HDR) + (size_t)ci * QSV_COMBO_WORDS;
+    static_assert(QSV_COMBO_WORDS == 2, "two mask words are spelled out below");
+    const unsigned long long m0 = uniform_u64(mk[0]), m1 = uniform_u64(mk[1]);
+    // the plain loop over the flat list (the shape the in-place interpreter was tuned in: anything cleverer -- iterating the
+    // set bits, a second copy of the loop -- cost more than it saved); an op this workgroup cannot fire costs one scalar
+    // bit test, its descriptor is never loaded
+    const int nops = (!INIT || live) ? nrounds : 0;
+    for (int i = 0; i < nops; ++i) {
+      const unsigned long long mw = i < 64 ? m0 : m1;
+      if (!((mw >> (i & 63)) & 1ull)) continue;
+      gen_op<R>(a, ops[i], base, lt);
     }
   } else {
     constexpr int NS = R + 1;

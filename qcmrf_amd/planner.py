@@ -20,6 +20,8 @@ next dense use is farthest away (never, if possible).
 """
 from __future__ import annotations
 
+import os
+
 import copy
 
 from . import ir
@@ -202,6 +204,10 @@ def choose_layout(ops, n_qubits, n_shards, layout="auto", lane_targets=True, dyn
         pure_ctrl = [q for q in live if heat[q] == 0]
         tgt = [q for q in live if heat[q] > 0]
         by_cold = sorted(tgt, key=lambda q: (heat[q], -dense_first.get(q, never), q))
+        if os.environ.get("QSV_PLANNER_CTRL_TOP", "1") == "0":       # experiment switch: the round-2 rule (coldest qubits on the lanes)
+            by_cold = sorted(live, key=lambda q: (heat[q], 0 if (uniform >> q) & 1 else 1, q))
+            pure_ctrl = []
+            tgt = live
         lanes = by_cold[:LANE_BITS]
         lanes += pure_ctrl[:LANE_BITS - len(lanes)]
         above = sorted((q for q in tgt if q not in lanes), key=lambda q: (-heat[q], dense_first.get(q, never), q))

@@ -77,6 +77,30 @@ def test_controlled_1q_and_mcx_with_flags(lib, n):
         assert np.abs(e.amplitudes() - ref).max() < TOL
 
 
+@pytest.mark.parametrize("mask,nt", [(1, 0), (1, 1), (0, 0)])
+def test_controls_inside_a_cache_line_as_a_mask(lib, mask, nt):
+    """controlled X / 2x2 with controls on address bits 0..2: the masked full-line sweep (k_pair_m, default) and the
+    enumerating form, plain and non-temporal, targets below, between and above the controls, +-control values"""
+    n = 15
+    rs = np.random.RandomState(5)
+    ref = rand_state(n, 13)
+    with lib.Engine(n) as e:
+        e.set_option("lowctl_mask", mask)
+        e.set_option("nontemporal", nt)
+        e.set_amplitudes(0, ref)
+        cases = [([1], 12), ([1, 5], 12), ([0, 2, 9], 4), ([2], 0), ([0, 1, 2], 14), ([1, 13], 2), ([2, 7, 11], 1), ([0], 1)]
+        for trial, (cs, t) in enumerate(cases * 2):
+            vals = rs.randint(0, 2, size=len(cs)).tolist()
+            if trial % 2:
+                e.apply_mcx(cs, t, vals)
+                sv.apply_mcx(ref, cs, t, vals)
+            else:
+                m = rand_u(1, 90 + trial)
+                e.apply_1q(t, m, cs, vals)
+                sv.apply_1q(ref, t, m, cs, vals)
+        assert np.abs(e.amplitudes() - ref).max() < TOL
+
+
 @pytest.mark.parametrize("n", [3, 9, 14])
 def test_diag_and_mcphase(lib, n):
     rs = np.random.RandomState(n)
