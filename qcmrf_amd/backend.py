@@ -107,7 +107,10 @@ class QsvBackend:
                 'trajectory' (mid-circuit measurements taken when they occur, measured qubits
                 released: n+2 live qubits for a QCMRF circuit, see qcmrf_amd.trajectory)
     comm        process group for one-process-per-GPU launches (qcmrf_amd.comm)
-    gather_counts  'root' (default: rank 0 returns the merged counts, the other ranks an empty dict) | 'all' 
+    gather_counts  'root' (default: rank 0 returns the merged counts, the other ranks an empty dict) | 'all'
+    spmd_ingest    (multi-rank) each rank reads 1/N of the circuit's composite blocks, one all-gather completes the program
+                   (default off: in the only rehearsal available -- ranks sharing one GPU -- the extra collective cost more
+                   than the reading it saved)
     device      HIP device of this rank when ``comm`` is given
     """
 
@@ -224,7 +227,7 @@ class QsvBackend:
         t0 = time.perf_counter()
         comm = opts["comm"] or SingleProcess()
         n_shards = comm.world if comm.world > 1 else len(opts["devices"])
-        ing, pl = self.compile(circuit, n_shards, ingest_comm=comm if (comm.world > 1 and opts.get("spmd_ingest", True) and not opts.get("_batch")) else None,
+        ing, pl = self.compile(circuit, n_shards, ingest_comm=comm if (comm.world > 1 and opts.get("spmd_ingest", False) and not opts.get("_batch")) else None,
                                **{k: opts[k] for k in ("fusion", "layout", "engine_options", "fold_fresh")})
         rec, data = program.encode(pl.ops)
         return ing, pl, rec, data, n_shards, time.perf_counter() - t0

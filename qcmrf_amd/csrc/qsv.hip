@@ -192,7 +192,7 @@ struct qsv_handle {
   int opt_blocksum_variant = 6;       // access pattern of the read-only passes (qsv_measure.inc): 2 wave-contiguous, 4 no grid-stride loop, 1 index swizzle
   int opt_swz = 1;                    // one-gate kernels: lane bit 5 of a wave access carries address bit 11 (swz_5_11)
   int opt_general_light_r = 5;        // tile a general pass with little arithmetic is padded to (its register TARGETS stay <= general_r)
-  int opt_pass_max_ops = 64;          // ops per k_multi pass at most
+  int opt_pass_max_ops = 56;          // ops per k_multi pass at most (34-qubit unfused stream: 56 -> 8 passes at 0.70 of peak, 827 ms; 64 -> 7 at 0.65, 783 ms; 96 -> 5 at 0.51, 712 ms)
   int opt_single_shortcut = 1;        // a pass of ONE op runs as its dedicated kernel (0: as a k_multi pass like any other -- an experiment)
   int opt_general_r = 4;              // ... of a GENERAL pass (masked ops / register selects); also the tile it is padded to
   int opt_pair_variant = 0;           // experiments: see run_single

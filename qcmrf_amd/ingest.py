@@ -542,7 +542,8 @@ def _walk_flat(circuit, out):
     promises the stream gate by gate).  Returns False (nothing emitted) if the circuit is not flat."""
     data = circuit.data
     try:
-        names = [ci.operation.name for ci in data]
+        gates = [ci.operation for ci in data]
+        names = [o.name for o in gates]
     except AttributeError:
         return False
     if not _FLAT_NAMES.issuperset(names):
@@ -550,6 +551,7 @@ def _walk_flat(circuit, out):
     qi, ci_map = _bit_maps(circuit)
     if qi is None:
         return False
+    qargs = [ci.qubits for ci in data]
     ops = out.ops
     pend, slot = {}, {}                    # wire -> [g, f, a_0, a_1, ...]; wire -> index of its placeholder in ops
     measured = out._measured
@@ -614,13 +616,16 @@ def _walk_flat(circuit, out):
 
     out.global_phase += float(getattr(circuit, "global_phase", 0.0) or 0.0)
     n_src = 0
-    conds = [ci.operation for ci in data if getattr(ci.operation, "condition", None) is not None]
+    try:
+        conds = [o for o in gates if o.condition is not None]
+    except AttributeError:                                   # no .condition attribute at all (Qiskit >= 2)
+        conds = [o for o in gates if getattr(o, "condition", None) is not None]
     if conds:
         raise ValueError("classically conditioned operation %r is not supported" % conds[0].name)
     pget = pend.get
-    for ci, name in zip(data, names):
+    for ci, name, gate, qa in zip(data, names, gates, qargs):
         if name == "rz" or name == "sx" or name == "x":
-            q = qi[id(ci.qubits[0])]
+            q = qi[id(qa[0])]
             if measured and q in measured:
                 raise ValueError("gate %r acts on qubit %d after it was measured; mid-circuit measurement "
                                  "with later use of the qubit is not supported" % (name, q))
@@ -634,7 +639,7 @@ def _walk_flat(circuit, out):
                 slot[q] = len(ops)
                 ops.append(None)
             if name == "rz":
-                lam = ci.operation.params[0]
+                lam = gate.params[0]
                 if type(lam) is not float:
                     try:
                         lam = float(lam)
@@ -676,8 +681,7 @@ def _walk_flat(circuit, out):
                 st.append(new)
             continue
         if name == "cx":
-            qs = ci.qubits
-            q, t = qi[id(qs[0])], qi[id(qs[1])]
+            q, t = qi[id(qa[0])], qi[id(qa[1])]
             if measured and (q in measured or t in measured):
                 raise ValueError("gate 'cx' acts on qubit %d after it was measured; mid-circuit measurement "
                                  "with later use of the qubit is not supported" % (q if q in measured else t))
@@ -696,7 +700,7 @@ def _walk_flat(circuit, out):
             ops.append(ir.Op("x", target=t, ctrls=(q,), vals=(1,)))
             continue
         if name == "measure":
-            q = qi[id(ci.qubits[0])]
+            q = qi[id(qa[0])]
             n_src += 1
             flush(q)
             c = ci_map[id(ci.clbits[0])]
