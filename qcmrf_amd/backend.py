@@ -244,7 +244,11 @@ class QsvBackend:
         if ing.global_phase and opts.get("apply_global_phase", True):
             from . import ir
             ph = np.exp(1j * ing.global_phase)
-            ops.append(ir.op_diag([0], [ph, ph]))
+            host = next((o for o in ops if o.kind == "diag"), None)
+            if host is not None:                             # rides in a diagonal that is there anyway (one factor fewer on the device)
+                host.table = host.table * ph
+            else:
+                ops.append(ir.op_diag([0], [ph, ph]))
         eo = opts.get("engine_options") or {}
         lane = bool(eo.get("lane_targets", 1)) and not eo.get("zero_tracking", 0)   # lane targets need a fully populated vector
         pl = planner.plan(ops, ing.num_qubits, n_shards, opts["layout"], lane_targets=lane,

@@ -1,6 +1,7 @@
 // qsv_kmulti.h -- the register-tiled multi-gate pass (k_multi) and its tile geometry.  Its own header so that
 // the instantiations compile in translation units of their own (qsv_kmulti_inst.h).
 #pragma once
+#include <cstddef>
 #include "qsv_common.h"
 
 // ---------------------------------------------------------------------------------------
@@ -18,20 +19,25 @@
 #define QSV_MULTI_MAXR 6
 #define QSV_MULTI_MAXLIST 10
 
-struct MultiOp {
-  int type;                       // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase | 4, 5: types 0, 2 on a lane bit
-  int bit;                        // register bit of the target (types 0, 2); lane bit (types 4, 5)
-  int uniform;                    // 1: table index (types 0, 1, 4) / control condition (2, 3, 5: rmask == 0) independent of the register bits
-  int nlist;                      // entries of pos[] (types 0, 1); types 2, 5: != 0 marks a plain X
-  int tab;                        // table offset in LDS, in complex128 units
+// Field order matters to the general pass: its interpreter reads an op's control words with scalar loads, and the scalar data
+// cache is small (16 KiB shared by a few CUs).  Everything a controlled X or a controlled phase needs -- the bulk of the reference's
+// unfused stream -- sits in the FIRST 64-byte line of the (64-byte aligned) descriptor: a 56-op pass then keeps 3.5 KiB of
+// descriptors hot instead of striding through 10 KiB with every op's words straddling two lines.
+struct alignas(64) MultiOp {
   int shape;                      // general passes: which of the eleven update shapes (GS_*) this op is
-  unsigned int rmask, rval;       // types 2,3: condition on the register index
+  int bit;                        // register bit of the target (types 0, 2); lane bit (types 4, 5)
+  int tab;                        // table offset in LDS, in complex128 units
+  int type;                       // 0 mux table | 1 diag table | 2 controlled 2x2 | 3 controlled phase | 4, 5: types 0, 2 on a lane bit
   unsigned long long tmask, tval; // types 2,3: condition on the lane/block part of the address
   unsigned long long rfire;       // types 2,3,5: bit j set <=> (j & rmask) == rval, j = register index of an amplitude
-  double m[8];                    // type 2: 2x2 row-major {re,im}; type 3: m[0..1] = phase
+  double m[8];                    // type 2: 2x2 row-major {re,im}; type 3: m[0..1] = phase (m[0..1] still in the first line)
+  int uniform;                    // 1: table index (types 0, 1, 4) / control condition (2, 3, 5: rmask == 0) independent of the register bits
+  int nlist;                      // entries of pos[] (types 0, 1); types 2, 5: != 0 marks a plain X
+  unsigned int rmask, rval;       // types 2,3: condition on the register index
   int regw[QSV_MULTI_MAXR];       // types 0,1: table-index weight of register bit c
   int pos[QSV_MULTI_MAXLIST];     // types 0,1: address bit of list entry e; -1 if it is a register bit
 };
+static_assert(sizeof(MultiOp) % 64 == 0 && offsetof(MultiOp, m) + 16 <= 64, "the hot words of a MultiOp share its first cache line");
 // update shapes of a general pass.  Gates on a register bit: table with one matrix per thread / per
 // pair, controlled X, one controlled matrix; then the ops without a register target: diagonal table
 // with one entry per thread / per amplitude, controlled phase, lane-bit gate as a table (per thread /

@@ -925,6 +925,8 @@ def fold_fresh(ops):
             mx = _as_mux(op) if dg is None else None
             if dg is not None:
                 q, t = _slice_zero(dg[0], dg[1], populated)
+                if q and not (t != t.ravel()[0]).any():
+                    q = ()                                  # a constant table is a number (a global phase), not a factor
                 if q:
                     factors.append(ir.op_diag(q, t.ravel()))
                     for x in q:
