@@ -8,7 +8,7 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 34
 C = wl.for_width(W)
 qc = QCMRF(C, wl.theta_halfnorm(wl.dimension(C)))
 be = QsvBackend()
-for cap in (40, 48, 56, 64, 80, 96, 112):
+for cap in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (40, 48, 56, 64, 80, 96, 112)):
     eo = {"pass_max_ops": cap}
     be.run(qc, shots=16, fusion=0, engine_options=eo)
     r = be.run(qc, shots=16, fusion=0, profile=True, engine_options=eo).result()

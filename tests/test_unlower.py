@@ -149,3 +149,43 @@ def test_flat_ingest_run_algebra_matches_matrix_products(seed):
             got = X if o.kind == "x" else np.diag(o.table) if o.kind == "diag" else o.mat
         got = np.exp(1j * ing.global_phase) * got
         assert np.abs(got - U).max() < 1e-12, (seed, trial, [ci.operation.name for ci in qc.data])
+
+
+def test_merge_diagonals_is_exact_and_lets_scattered_phases_meet():
+    """passes.merge_diagonals: diagonals travel forward past everything that is diagonal on their qubits (multiplexer selects,
+    other diagonals) and multiply into a waiting one on the same qubits or a superset; a dense gate on one of their qubits
+    stops them.  Exact on random lists; a T on a variable wire and its inverse three gates later cancel."""
+    rs = np.random.RandomState(3)
+
+    def rmux(ctrls, t):
+        mats = []
+        for _ in range(2 ** len(ctrls)):
+            q, _ = np.linalg.qr(rs.randn(2, 2) + 1j * rs.randn(2, 2))
+            mats.append(q)
+        return ir.op_mux(ctrls, t, np.array(mats))
+    n = 5
+    for trial in range(20):
+        ops = []
+        for _ in range(12):
+            r = rs.randint(4)
+            q = [int(x) for x in rs.permutation(n)]
+            if r == 0:
+                k = int(rs.randint(1, 4))
+                ops.append(ir.op_diag(q[:k], np.exp(1j * rs.uniform(-3, 3, size=2 ** k))))
+            elif r == 1:
+                ops.append(ir.op_mcphase(q[:rs.randint(1, 4)], float(rs.uniform(-3, 3))))
+            elif r == 2:
+                ops.append(rmux(q[:2], q[2]))
+            else:
+                ops.append(ir.op_x(q[0], q[1:2]))
+        out = passes.merge_diagonals(ops)
+        assert np.abs(unitary_of(out, n) - unitary_of(ops, n)).max() < 1e-12
+        assert sum(o.kind in ("diag", "mcphase") for o in out) <= sum(o.kind in ("diag", "mcphase") for o in ops)
+    t = np.exp(0.25j * np.pi)
+    ops = [ir.op_diag([0], [1, t]), rmux([0, 1], 3), ir.op_diag([1, 0], [1, 1, 1, -1]), rmux([0], 4), ir.op_diag([0], [1, t.conjugate()])]
+    out = passes.merge_diagonals(ops)
+    assert [o.kind for o in out] == ["mux", "mux", "diag"] and set(out[2].qubits) == {0, 1}
+    assert np.abs(unitary_of(out, 5) - unitary_of(ops, 5)).max() < 1e-14
+    # fold_fresh: a constant table is a number, not a device factor
+    folded = passes.fold_fresh([ir.op_init(0b11), ir.op_diag([0], [t, t]), ir.op_diag([1], [1, t])])
+    assert [o.kind for o in folded] == ["init", "diag"] and np.allclose(folded[1].table, [t, t * t])
