@@ -920,6 +920,121 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3(cplx* __restrict__ amp, ui
 }
 
 // ---------------------------------------------------------------------------------------
+// k_kq_mfma3w<K>: the three-product kernel with TWO 16-column batches per step, loaded and stored 32 groups wide.
+// k_kq_mfma3's operand layout makes a wave access four 256-byte runs (16 groups x 4 k-rows), and that -- not the
+// matrix cores, which idle 58 % of the time -- is what holds every variant of it at 0.64-0.71 of the stream.  Here
+// lane l reads for group (l & 31) the rows t = 4 ks + (l >> 5) and t = 4 ks + 2 + (l >> 5): each load instruction is
+// two 512-byte runs, the pattern that streams best on this chip.  Two CDNA4 lane-swap instructions per
+// dword then turn the pair (x, y) into the B operands of the two batches,
+//     rows of 16 lanes:  x = [g0 k0, g1 k0, g0 k1, g1 k1]   y = [g0 k2, g1 k2, g0 k3, g1 k3]     (g0 = groups 0..15, g1 = 16..31)
+//     v_permlane32_swap: x = [g0 k0, g1 k0, g0 k2, g1 k2]   y = [g0 k1, g1 k1, g0 k3, g1 k3]
+//     v_permlane16_swap: x = [g0 k0, g0 k1, g0 k2, g0 k3]   y = [g1 k0, g1 k1, g1 k2, g1 k3]
+// and the inverse pair turns the two batches' results (same row structure: D row = (lane >> 4) + 4 r) back into
+// 512-byte runs for the stores.  A fragments in LDS as in k_kq_mfma3<ALDS>.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void lanes_to_batches(double& x, double& y) {
+  int xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  auto a = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+  auto c = __builtin_amdgcn_permlane16_swap(a[0], a[1], false, false);
+  auto d = __builtin_amdgcn_permlane16_swap(b[0], b[1], false, false);
+  x = __hiloint2double(d[0], c[0]);
+  y = __hiloint2double(d[1], c[1]);
+}
+__device__ __forceinline__ void batches_to_lanes(double& x, double& y) {
+  int xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  auto a = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+  auto c = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);
+  auto d = __builtin_amdgcn_permlane32_swap(b[0], b[1], false, false);
+  x = __hiloint2double(d[0], c[0]);
+  y = __hiloint2double(d[1], c[1]);
+}
+
+template <int K, bool NT>
+__global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3w(cplx* __restrict__ amp, uint64_t nsteps,
+                                                       BitIns ins, KqOffs offs,
+                                                       const double* __restrict__ ur,
+                                                       const double* __restrict__ ui) {
+  constexpr int D = 1 << K, MB = D / 16, KS = D / 4;
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4;
+  extern __shared__ double lds_a[];                        // [mb][ks][3][64 lanes]: (Ur + Ui), Ur, Ui fragments
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
+        const double r = ur[i * D + k], m = ui[i * D + k];
+        double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lane;
+        p[0] = r + m; p[64] = r; p[128] = m;
+      }
+  }
+  __syncthreads();
+  const uint64_t okh = offs.off[lane >> 5];                // the lane's part of a row offset: bit 0 of t
+  const uint64_t o2 = offs.off[2];
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (QSV_TPB / 64) + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * (QSV_TPB / 64);
+  for (uint64_t st = wave0; st < nsteps; st += nwaves) {
+    const uint64_t base = ins_bits(st * 32 + (lane & 31), ins) | okh;
+    cplx x[KS], y[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const cplx* px = amp + (base | offs.off[ks * 4]);
+      x[ks] = NT ? ld_nt(px) : *px;
+      y[ks] = NT ? ld_nt(px + o2) : px[o2];                // (o2 is a single bit not set in base | off[4 ks]: + is |)
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      lanes_to_batches(x[ks].x, y[ks].x);
+      lanes_to_batches(x[ks].y, y[ks].y);
+    }
+    int lofs = lane;
+    asm volatile("" : "+v"(lofs));                          // re-read the fragments every step (hoisted they are 96 VGPRs)
+    cplx o[2][MB][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f64x4 t1[MB], t2[MB], t3[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        t1[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        t2[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        t3[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const cplx v = b ? y[ks] : x[ks];
+        const double bre = v.x, dif = v.y - v.x, sum = v.x + v.y;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lofs;
+          t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], bre, t1[mb], 0, 0, 0);
+          t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[64], dif, t2[mb], 0, 0, 0);
+          t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[128], sum, t3[mb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[b][mb][r] = make_double2(t1[mb][r] - t3[mb][r], t1[mb][r] + t2[mb][r]);
+    }
+    // (one 16-row output block at a time -- fewer accumulators live -- was tried for K = 5: hipcc then keeps MORE alive, 174 VGPRs)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        batches_to_lanes(o[0][mb][r].x, o[1][mb][r].x);
+        batches_to_lanes(o[0][mb][r].y, o[1][mb][r].y);
+        cplx* ps = amp + (base | offs.off[mb * 16 + 4 * r]);
+        if (NT) { st_nt(ps, o[0][mb][r]); st_nt(ps + o2, o[1][mb][r]); }
+        else    { *ps = o[0][mb][r]; ps[o2] = o[1][mb][r]; }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_kq_tile<K>: dense 2^K x 2^K (K <= 3) on the vector units, one thread per group of 2^K amplitudes
 // in registers, one group per thread and no grid-stride loop (the stream shape of every other sweep here),
 // matrix rows read from LDS as broadcasts.  8 * 2^K flop per 32 B is 2 flop/B at K = 3: a quarter of

@@ -562,6 +562,7 @@ def _walk_flat(circuit, out):
     dense = set()                          # wires that are a dense target after their opening run (cx target, non-diagonal run)
     hrest = {}                             # wire -> Hadamard-like gates after its opening run (a general 2x2 counts as two)
     gph = 0.0
+    cxs = {}
 
     def flush(q):
         nonlocal gph
@@ -697,7 +698,10 @@ def _walk_flat(circuit, out):
                 role[t] = "t"
                 touched.add(t)
             dense.add(t)
-            ops.append(ir.Op("x", target=t, ctrls=(q,), vals=(1,)))
+            o = cxs.get((q, t))                               # one op object per (control, target) of THIS walk: the passes read them, never write
+            if o is None:
+                o = cxs[(q, t)] = ir.Op("x", target=t, ctrls=(q,), vals=(1,))
+            ops.append(o)
             continue
         if name == "measure":
             q = qi[id(qa[0])]

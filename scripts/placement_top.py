@@ -45,7 +45,16 @@ cases = [
     (R(20, 24), [], [], "reg 20-24"),
     (R(T - 4, T), [12, 13, 14], [0, 1, 2], "reg top 5 + bor 12-14 + stat 0-2"),
     (R(T - 4, T), [11, 12, 13], [], "reg top 5 + bor 11-13"),
+    # round 3: mixed tiles with the bench pass's lane targets
+    ([9, 10, 11, T - 1, T], [6, 7, 8], [0, 1, 2], "reg 9-11 + top 2, bor 6-8, stat 0-2"),
+    ([6, 7, 8, T - 1, T], [9, 10, 12], [0, 1, 2], "reg 6-8 + top 2, bor 9,10,12, stat 0-2"),
+    ([6, 7, T - 2, T - 1, T], [8, 9, 10], [0, 1, 2], "reg 6,7 + top 3, bor 8-10, stat 0-2"),
+    (R(6, 10), [12, 13, 14], [0, 1, 2], "reg 6-10, bor 12-14, stat 0-2"),
+    (R(T - 3, T) + [6], [7, 8, 9], [0, 1, 2], "reg 6 + top 4, bor 7-9, stat 0-2"),
 ]
+if os.environ.get("QSV_CASES"):
+    pick = [int(x) for x in os.environ["QSV_CASES"].split(",")]
+    cases = [cases[i] for i in pick]
 for init in ((False,) if os.environ.get('QSV_RW_ONLY') else (False, True)):
     for regs, bor, stat, label in cases:
         run(regs, bor, stat, init, label)
