@@ -236,7 +236,7 @@ class QsvBackend:
         """ingest + passes + plan only (no GPU): returns (Ingested, Plan)"""
         opts = dict(self.options)
         opts.update(options)
-        ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1, comm=opts.get("ingest_comm"))
+        ing = _ingest.ingest(circuit, peephole=opts["fusion"] >= 1, comm=opts.get("ingest_comm"), compact=opts["fusion"] >= 3)
         # every qubit of a dense window has to be local to a shard at the same time
         g = max(1, int(n_shards)).bit_length() - 1
         ops = passes.optimise(ing.ops, level=opts["fusion"], fresh=bool(opts.get("fold_fresh", True)),

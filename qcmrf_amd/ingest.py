@@ -517,6 +517,10 @@ def _walk(circuit, qmap, cmap, out, depth):
 
 
 _FLAT_NAMES = frozenset(("rz", "sx", "x", "cx", "id", "measure", "barrier", "delay"))
+class _NotCompact(Exception):
+    """the flat walk met something it has no compact record for: redo it with ir.Op objects"""
+
+
 _PI = math.pi
 _TWO_PI = 2.0 * math.pi
 _HALF_PI = 0.5 * math.pi
@@ -527,7 +531,7 @@ def _wrap(a):
     return a - _TWO_PI * round(a / _TWO_PI)
 
 
-def _walk_flat(circuit, out):
+def _walk_flat(circuit, out, compact=False):
     """A circuit already lowered to the reference's basis {cx, id, rz, sx, x} (run_experiment.py:52) is
     thousands of one-qubit gates between CX gates.  Every maximal run of them on a wire is kept as what it IS
     while walking -- a global phase, an X flag and the phase angles between its Hadamards,
@@ -539,7 +543,9 @@ def _walk_flat(circuit, out):
     where it BEGINS (right behind the previous gate on its wire) as ONE op that carries its angles (ir.classify_1q
     forms: 'D', 'A', 'h', 'G'; matrices are built only if somebody asks): 5.7-7.4 k instructions of the 34-qubit
     circuit become ~3 k ops without a single complex multiplication.  Exact; used at fusion >= 1 only (fusion 0
-    promises the stream gate by gate).  Returns False (nothing emitted) if the circuit is not flat."""
+    promises the stream gate by gate).  Returns False (nothing emitted) if the circuit is not flat.
+    compact: ``out.ops`` holds plain tuples (unlower's gate records) instead of ir.Op objects -- what the symbolic
+    re-assembly reads, at a fraction of the cost of 5 k objects; ``unlower.rec_to_op`` turns one into the op it stands for."""
     data = circuit.data
     try:
         gates = [ci.operation for ci in data]
@@ -579,13 +585,13 @@ def _walk_flat(circuit, out):
                     dense.add(q)
                 if abs(a) < 1e-15:
                     gph += g
-                    ops[i] = ir.Op("x", target=q)
+                    ops[i] = ("x", q) if compact else ir.Op("x", target=q)
                 else:
-                    ops[i] = ir.Op("u", target=q, cls=("A", _wrap(g), a), label="run")
+                    ops[i] = ("a", q, _wrap(g), a) if compact else ir.Op("u", target=q, cls=("A", _wrap(g), a), label="run")
             elif abs(a) < 1e-15:
                 gph += g                   # the run multiplied out to a number
             else:
-                ops[i] = ir.Op("diag", qubits=(q,), cls=("D", _wrap(g), a))
+                ops[i] = ("d", q, _wrap(g), a) if compact else ir.Op("diag", qubits=(q,), cls=("D", _wrap(g), a))
             return
         opening = leadslot.get(q) == i
         if not opening:
@@ -598,6 +604,8 @@ def _walk_flat(circuit, out):
             cls = ("G", _wrap(g + a2), _wrap(a1 + _PI), _wrap(a0), _wrap(-a2)) if f else ("G", _wrap(g), _wrap(a1), _wrap(a0), _wrap(a2))
         else:
             # three or more Hadamards left in one run (generic angles between them): multiply it out after all
+            if compact:
+                raise _NotCompact()
             m = np.array([[1.0, 0.0], [0.0, cmath.exp(1j * st[2])]], dtype=np.complex128)
             for a in st[3:]:
                 m = np.array([[1.0, 0.0], [0.0, cmath.exp(1j * a)]]) @ ir.FIXED_1Q["h"] @ m
@@ -611,7 +619,10 @@ def _walk_flat(circuit, out):
             if cls[0] in ("D", "A"):       # (cannot happen for three honest Hadamards, but stay exact)
                 ops[i] = ir.Op("diag", qubits=(q,), cls=cls) if cls[0] == "D" else ir.Op("u", target=q, cls=cls, label="run")
                 return
-        ops[i] = ir.Op("u", target=q, cls=cls, label="run")
+        if compact:
+            ops[i] = ("h", q, cls[1], cls[2], cls[3]) if cls[0] == "h" else ("g", q, cls[1], cls[2], cls[3], cls[4])
+        else:
+            ops[i] = ir.Op("u", target=q, cls=cls, label="run")
         if not opening:
             hrest[q] = hrest.get(q, 0) + (1 if cls[0] == "h" else 2)
 
@@ -700,7 +711,7 @@ def _walk_flat(circuit, out):
             dense.add(t)
             o = cxs.get((q, t))                               # one op object per (control, target) of THIS walk: the passes read them, never write
             if o is None:
-                o = cxs[(q, t)] = ir.Op("x", target=t, ctrls=(q,), vals=(1,))
+                o = cxs[(q, t)] = ("c", q, t) if compact else ir.Op("x", target=t, ctrls=(q,), vals=(1,))
             ops.append(o)
             continue
         if name == "measure":
@@ -720,16 +731,18 @@ def _walk_flat(circuit, out):
     out.global_phase += gph
     lead = {q: ops[i] for q, i in leadslot.items() if ops[i] is not None}
     out.ops = [o for o in ops if o is not None]
-    out.flat = {"lead": lead, "role": role, "dense": dense, "hrest": hrest}
+    out.flat = {"lead": lead, "role": role, "dense": dense, "hrest": hrest, "compact": bool(compact)}
     out.n_source_ops += n_src
     return True
 
 
-def ingest(circuit, peephole=False, keep_measures=False, comm=None):
+def ingest(circuit, peephole=False, keep_measures=False, comm=None, compact=False):
     """peephole=True additionally folds X..X . MCX . X..X definitions (Qiskit's AND with negative
     flags) into one MCX with negated controls while walking -- exact, and 5x fewer ops to fuse.
     comm (a process group of world > 1, every rank calling with the same circuit): the composite top-level blocks are
-    read by one rank each and exchanged in ONE all-gather; the result is the same Ingested on every rank."""
+    read by one rank each and exchanged in ONE all-gather; the result is the same Ingested on every rank.
+    compact (basis-gate circuits only): ``ops`` are unlower's gate records (tuples), ``flat["compact"]`` says so; only
+    ``passes.optimise(..., flat=)`` at level 3 understands them."""
     nq = int(circuit.num_qubits)
     nc = int(getattr(circuit, "num_clbits", 0))
     out = Ingested(nq, nc)
@@ -742,7 +755,10 @@ def ingest(circuit, peephole=False, keep_measures=False, comm=None):
     flat = False
     if peephole and not keep_measures:
         try:
-            flat = _walk_flat(circuit, out)
+            flat = _walk_flat(circuit, out, compact=compact and not keep_measures)
+        except _NotCompact:
+            out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops, out.flat = [], {}, set(), 0.0, 0, None
+            flat = _walk_flat(circuit, out, compact=False)
         except KeyError:                     # bits that are equal to, but not, the circuit's own objects: take the general walk
             out.ops, out.measure, out._measured, out.global_phase, out.n_source_ops, out.flat = [], {}, set(), 0.0, 0, None
     if not flat:

@@ -1320,7 +1320,23 @@ def optimise(ops, level=3, kmax=10, smax=8, fresh=True, dense_kmax=5, flat=None)
 def _optimise(ops, level, kmax, smax, dense_kmax=5, flat=None):
     if level <= 0:
         return [ir.op_init(0)] + list(ops)
-    if flat is not None:
+    compact = flat is not None and flat.get("compact")
+    if compact:
+        # ops are unlower's gate records: the wires that open with a Hadamard-like run are those whose record says so
+        from .unlower import rec_to_op
+        lead_ops = flat["lead"]
+        cands = set(q for q, r in lead_ops.items() if r[0] == "h")         # an 'h' record IS e^{ig} D(b) H D(a)
+        hold0 = flat["dense"] & cands
+        if level < 3 or hold0 != cands or not cands:         # not the lowered case after all: the passes below want ir.Op objects
+            conv = {}
+            for r in ops:
+                if id(r) not in conv:
+                    conv[id(r)] = rec_to_op(r) if type(r) is tuple else r
+            flat = dict(flat, compact=False, lead={q: conv[id(r)] for q, r in lead_ops.items()})
+            return _optimise([conv[id(r)] for r in ops], level, kmax, smax, dense_kmax, flat)
+        skip = set(map(id, lead_ops.values()))
+        lead = rest = None
+    elif flat is not None:
         lead_ops = flat["lead"]
         lead = {q: np.array(_as_1q(o)[1], dtype=np.complex128) for q, o in lead_ops.items()}
         skip = set(map(id, lead_ops.values()))
@@ -1348,7 +1364,7 @@ def _optimise(ops, level, kmax, smax, dense_kmax=5, flat=None):
             if role.get(q) == "t" and hrest.get(q, 0) > 0:
                 keep.add(id(lead_ops[q]))
             else:
-                front.append(lead_ops[q])
+                front.append(rec_to_op(lead_ops[q]) if compact else lead_ops[q])
         body = [o for o in ops if id(o) not in skip or id(o) in keep]
     else:
         front, rest = hoist_leading(ops, split=(lead, rest), lone_h=True)

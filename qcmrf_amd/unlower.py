@@ -176,6 +176,35 @@ def _close_monomial(dep, y, h):
     return res
 
 
+# ---- compact gate records ----------------------------------------------------------------------------------------
+# ingest's flat walk can hand over plain tuples instead of ir.Op objects (thousands of gates per circuit; an Op costs
+# several times a tuple, and the window reads only these fields):
+#     ('c', control, target)        cx               ('x', q)                     x
+#     ('d', q, g, a)                e^{ig} D(a)      ('a', q, g, a)               X e^{ig} D(a)
+#     ('h', q, g, al, be)           e^{ig} D(al) H D(be)
+#     ('g', q, g, th, b1, a2)       e^{ig} D(a2) H D(th) H D(b1)
+def rec_to_op(rec):
+    """the ir.Op a record stands for (fallbacks, leading runs, raw emission)"""
+    tag = rec[0]
+    if tag == "c":
+        return Op("x", target=rec[2], ctrls=(rec[1],), vals=(1,))
+    if tag == "x":
+        return Op("x", target=rec[1])
+    if tag == "d":
+        return Op("diag", qubits=(rec[1],), cls=("D", rec[2], rec[3]))
+    if tag == "a":
+        return Op("u", target=rec[1], cls=("A", rec[2], rec[3]), label="run")
+    if tag == "h":
+        return Op("u", target=rec[1], cls=("h", rec[2], rec[3], rec[4]), label="run")
+    return Op("u", target=rec[1], cls=("G", rec[2], rec[3], rec[4], rec[5]), label="run")
+
+
+def _support(item):
+    if type(item) is tuple:
+        return (item[1], item[2]) if item[0] == "c" else (item[1],)
+    return item.support()
+
+
 def _cls_of(op):
     """the angle form of a one-qubit gate (ir.classify_1q), cached on the op; ('?',) if it has none"""
     c = op.cls
@@ -303,7 +332,7 @@ class _Window:
         self.nops += 1
         self.last[q] = self.nops
         for op in held.pop(q, ()):
-            r = self.one_qubit(op, q)
+            r = self.one_rec(op, q) if type(op) is tuple else self.one_qubit(op, q)
             if r != OK:
                 return r
         return OK
@@ -316,6 +345,101 @@ class _Window:
             self.moved.discard(q)
         else:
             self.moved.add(q)
+
+    def one_rec(self, rec, q):
+        """a one-qubit record on a wire of the window"""
+        tag = rec[0]
+        if tag == "d":
+            self.gph += rec[2]
+            if rec[3]:
+                self.padd(self.tt[q], rec[3])
+            return OK
+        if tag == "h":
+            self.gph += rec[2]
+            return self.hadamard_like(q, rec[3], rec[4])
+        if tag == "x":
+            self.tt[q] ^= ALL
+            self.touch(q)
+            return OK
+        if tag == "a":
+            self.gph += rec[2]
+            if rec[3]:
+                self.padd(self.tt[q], rec[3])
+            self.tt[q] ^= ALL
+            self.touch(q)
+            return OK
+        # 'g': two Hadamard-like gates in a row
+        self.gph += rec[2]
+        r = self.hadamard_like(q, rec[3], rec[4])
+        if r != OK:
+            return r
+        if q not in self.tt:
+            e = cmath.exp(1j * rec[5])
+            self.emitted.append(ir.op_u(q, [[ir.SQ2, ir.SQ2], [ir.SQ2 * e, -ir.SQ2 * e]], label="run"))
+            return OK
+        return self.hadamard_like(q, rec[5], 0.0)
+
+    def feed_rec(self, rec, held):
+        """``feed`` for a compact record"""
+        tag = rec[0]
+        slot = self.slot
+        if tag == "c":
+            c, t = rec[1], rec[2]
+            if c in slot and t in slot:
+                tt = self.tt
+                b = tt[t] ^ tt[c]
+                tt[t] = b
+                b ^= VAR[slot[t]]
+                if b == 0 or b == ALL:
+                    self.moved.discard(t)
+                else:
+                    self.moved.add(t)
+                return OK
+            wires = (c, t)
+            new = [w for w in wires if w not in slot]
+            if slot and self.clean():
+                return BOUNDARY
+            if any(w in self.retired for w in new):
+                return STUCK
+            if len(new) > len(self.free) and not self.evict(len(new), wires):
+                return STUCK
+            for w in new:
+                if self.join(w, held, wires) != OK:
+                    return STUCK
+            if c not in slot or t not in slot:
+                return STUCK
+            tt = self.tt
+            tt[t] ^= tt[c]
+            self.touch(t)
+            return OK
+        q = rec[1]
+        if q in slot:
+            if tag == "d":                                   # (one_rec and padd, in line: the most frequent record after cx)
+                a = rec[3]
+                g = self.gph + rec[2]
+                T = self.tt[q]
+                if T & 1:
+                    T ^= ALL
+                    g += a
+                    a = -a
+                self.gph = g if -64.0 < g < 64.0 else _mod2pi(g)
+                if T and a:
+                    ph = self.ph
+                    v = ph.get(T)
+                    if v is None:
+                        ph[T] = a
+                    else:
+                        v += a
+                        if abs(v - TWO_PI * round(v / TWO_PI)) < 1e-13:
+                            del ph[T]
+                        else:
+                            ph[T] = v
+                return OK
+            return self.one_rec(rec, q)
+        if q in self.retired:
+            return BOUNDARY if self.clean() else STUCK
+        held.setdefault(q, []).append(rec)                  # commutes with the window: waits for its wire
+        return OK
 
     def one_qubit(self, op, q):
         if op.kind == "x":
@@ -654,7 +778,7 @@ def _run(ops):
 
     def release(wires=None):
         for q in (sorted(held) if wires is None else wires):
-            out.extend(held.pop(q, ()))
+            out.extend(rec_to_op(o) if type(o) is tuple else o for o in held.pop(q, ()))
 
     def mark():
         return {q: list(v) for q, v in held.items()}, ctx.snapshot()
@@ -669,7 +793,7 @@ def _run(ops):
         nonlocal gph
         w = _Window(ctx)
         for op in ops[lo:hi]:
-            r = w.feed(op, held)
+            r = w.feed_rec(op, held) if type(op) is tuple else w.feed(op, held)
             assert r == OK, r
         gph = _mod2pi(gph + w.flush(out))
 
@@ -678,17 +802,21 @@ def _run(ops):
         nonlocal n_raw
         ctx.drain(out)
         for op in ops[lo:hi]:
-            release(op.support())
+            sup = _support(op)
+            release(sup)
+            if type(op) is tuple:
+                op = rec_to_op(op)
             out.append(op)
-            n_raw += len(op.support()) > 1 or op.kind == "u"
+            n_raw += len(sup) > 1 or op.kind == "u"
 
+    recs = n > 0 and type(ops[0]) is tuple                # compact records (all of them) or ir.Op objects (all of them)
     i = w0 = last_clean = 0
     win = _Window(ctx)
     m0 = mark()
     while i <= n:
         r = OK
         if i < n:
-            feed, moved, br = win.feed, win.moved, win.br   # the common case in a tight loop: gates the window takes
+            feed, moved, br = (win.feed_rec if recs else win.feed), win.moved, win.br   # the common case in a tight loop: gates the window takes
             while i < n:
                 r = feed(ops[i], held)
                 if r:
@@ -706,7 +834,7 @@ def _run(ops):
             continue
         if r == BOUNDARY:
             gph = _mod2pi(gph + win.flush(out))
-            if i < n and any(q in win.retired for q in ops[i].support()):
+            if i < n and any(q in win.retired for q in _support(ops[i])):
                 ctx.drain(out)                           # a wire that left through a multiplexer comes back: it is no reference value any more
             win, w0, last_clean, m0 = _Window(ctx), i, i, mark()
             if i == n:

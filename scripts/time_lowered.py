@@ -7,14 +7,15 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _qiskit_shapes import lower_like_qiskit
 from qcmrf_amd import QCMRF, workloads as wl, passes as P, ingest as I, planner, program
 from qcmrf_amd.transpile import transpile
+COMPACT = os.environ.get("QSV_COMPACT", "1") != "0"      # what backend.compile asks for at fusion 3
 name, C = wl.baseline_config(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
 qc = QCMRF(C, wl.theta_halfnorm(wl.dimension(C)))
 for label, t in (("nested (as constructed)", qc), ("hand lowering", transpile(qc)), ("transpiler-shaped", lower_like_qiskit(qc))):
     N = 5
     for _ in range(2):
-        ing = I.ingest(t, peephole=True); ops = P.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
+        ing = I.ingest(t, peephole=True, compact=COMPACT); ops = P.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
     t0 = time.perf_counter()
-    for _ in range(N): ing = I.ingest(t, peephole=True)
+    for _ in range(N): ing = I.ingest(t, peephole=True, compact=COMPACT)
     t1 = time.perf_counter()
     for _ in range(N): ops = P.optimise(ing.ops, level=3, fresh=True, flat=ing.flat)
     t2 = time.perf_counter()

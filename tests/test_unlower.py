@@ -189,3 +189,37 @@ def test_merge_diagonals_is_exact_and_lets_scattered_phases_meet():
     # fold_fresh: a constant table is a number, not a device factor
     folded = passes.fold_fresh([ir.op_init(0b11), ir.op_diag([0], [t, t]), ir.op_diag([1], [1, t])])
     assert [o.kind for o in folded] == ["init", "diag"] and np.allclose(folded[1].table, [t, t * t])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_compact_gate_records_are_the_same_circuit(seed):
+    """ingest(compact=True) hands unlower plain tuples instead of ir.Op objects (what backend.compile asks for at
+    fusion 3): same unitary record by record, same re-assembly, and the passes fall back to ops below level 3"""
+    n = 4 + seed % 3
+    qc = random_structured(n, 30, 300 + seed)
+    for t in (transpile(qc), lower_like_qiskit(qc)):
+        a, b = ingest(t, peephole=True), ingest(t, peephole=True, compact=True)
+        assert b.flat["compact"] and not a.flat["compact"] and all(type(r) is tuple for r in b.ops)
+        assert abs(a.global_phase - b.global_phase) < 1e-14 and len(a.ops) == len(b.ops)
+        conv = [unlower.rec_to_op(r) for r in b.ops]
+        want = unitary_of(a.ops, n)
+        assert np.abs(unitary_of(conv, n) - want).max() < 1e-13
+        out, _ = unlower.unlower(b.ops)
+        assert all(isinstance(o, ir.Op) for o in out)
+        assert np.abs(unitary_of(out, n) - want).max() < 1e-11
+        for level in (1, 2, 3):
+            oa = passes.optimise(a.ops, level=level, fresh=True, flat=a.flat)
+            ob = passes.optimise(b.ops, level=level, fresh=True, flat=b.flat)
+            assert [o.kind for o in oa] == [o.kind for o in ob], level
+            assert oa[0].mask == ob[0].mask
+            assert np.abs(unitary_of(oa, n) - unitary_of(ob, n)).max() < 1e-11
+
+
+def test_compact_records_keep_mid_circuit_measures_out():
+    """keep_measures wants ir.Op('measure') in the stream: the flat walk stays with ops then"""
+    qc = QuantumCircuit(3, 3)
+    qc.h(0); qc.cx(0, 1); qc.cx(1, 2); qc.measure(1, 1)
+    t = transpile(qc)
+    ing = ingest(t, peephole=True, keep_measures=True, compact=True)
+    assert ing.flat is None or not ing.flat["compact"]
+    assert all(isinstance(o, ir.Op) for o in ing.ops)
