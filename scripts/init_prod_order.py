@@ -15,9 +15,11 @@ be = QsvBackend()
 be.run(qc, shots=4096, seed_simulator=1).result()
 
 
-def go(label, circ, n, **kw):
+def go(label, circ, n, gap_ms=0.0, **kw):
     row = []
     for i in range(n):
+        if gap_ms:
+            time.sleep(gap_ms * 1e-3)                      # an idle device between runs, as a slow host compile leaves it
         t0 = time.perf_counter()
         r = be.run(circ, shots=4096, seed_simulator=10 + i, **kw).result()
         dt = (time.perf_counter() - t0) * 1e3
@@ -30,6 +32,8 @@ def go(label, circ, n, **kw):
 for rnd in range(2):
     go("constructed", qc, 5)
     go("lowered", low, 5)
+    for gap in (5, 10, 20, 100):
+        go("constructed, %d ms idle before" % gap, qc, 5, gap_ms=gap)
     go("constructed profile=True", qc, 5, profile=True)
     go("lowered profile=True", low, 5, profile=True)
     go("lowered zero_tracking=0 profile", low, 3, profile=True, engine_options={"zero_tracking": 0})
