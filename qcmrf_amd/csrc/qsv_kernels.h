@@ -1035,6 +1035,120 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_mfma3w(cplx* __restrict__ amp, u
 }
 
 // ---------------------------------------------------------------------------------------
+// k_kq_lds<K>: the three-product kernel with the batch STAGED THROUGH LDS, so that what a wave asks of memory is as
+// contiguous as the placement of the targets allows -- not what the MFMA operand layout dictates.
+// A batch is 16 groups x 2^K rows = 2^(K+4) amplitudes, each named by K + 4 index bits (4 group bits, K row bits),
+// every one of which is one address bit.  Sorted by that address bit, the lowest six go to the LANE and the rest to the
+// load instruction's number: targets 0..4 make a wave load ONE 1 KiB run (the operand layout: sixteen 64-byte pieces),
+// targets (1, 6, 11, 17, 27) two 512-byte runs (four 128-byte ones).  The wave writes what it loaded into its own 2^K
+// rows x 16 columns image in LDS (row stride 272 B: conflict-free from both sides), reads the B operands
+// of the 2^K / 4 slices from there, leaves the results in the same image and stores them by the same map.  A wave's LDS
+// operations execute in order and no other wave touches its image: no barrier inside the loop.  The next batch's loads
+// are in flight during the products.  A fragments in LDS as in k_kq_mfma3<ALDS>.  NW waves per workgroup: LDS, not
+// registers, sets the occupancy (K = 5: 24 KiB fragments + NW x 8.5 KiB).
+// ---------------------------------------------------------------------------------------
+#define QSV_KQ_LDS_RS 272
+struct KqLds {
+  uint64_t goff_i[8];            // instruction i: its part of the amplitude index
+  uint64_t lane_goff[6];         // lane bit n: its part of the amplitude index
+  uint32_t loff_i[8];            // ... and of the byte offset in the image (row * 272 + column * 16)
+  uint32_t lane_loff[6];
+};
+template <int K, bool NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint64_t nbatch, BitIns ins, KqLds lay,
+                                                    const double* __restrict__ ur, const double* __restrict__ ui) {
+  constexpr int D = 1 << K, MB = D / 16, KS = D / 4, NI = D / 4, RS = QSV_KQ_LDS_RS;
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4;
+  extern __shared__ double lds_a[];                        // [mb][ks][3][64 lanes]: (Ur + Ui), Ur, Ui fragments; then NW images
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int i = mb * 16 + (lane & 15), k = ks * 4 + kq;
+        const double r = ur[i * D + k], m = ui[i * D + k];
+        double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lane;
+        p[0] = r + m; p[64] = r; p[128] = m;
+      }
+  }
+  __syncthreads();
+  char* image = reinterpret_cast<char*>(lds_a + MB * KS * 3 * 64) + (threadIdx.x >> 6) * (D * RS);
+  uint64_t gl = 0;
+  uint32_t ll = 0;
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+    if ((lane >> n) & 1) { gl |= lay.lane_goff[n]; ll += lay.lane_loff[n]; }
+  char* pm = image + ll;                                    // memory order: where this lane's loads land
+  char* po = image + kq * RS + (lane & 15) * 16;            // operand order: row kq of a slice, column lane & 15
+  const uint64_t wave0 = (uint64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+  const uint64_t nwaves = (uint64_t)gridDim.x * NW;
+  uint64_t bt = wave0;
+  uint64_t base = 0;
+  cplx nxt[NI];
+  if (bt < nbatch) {
+    base = ins_bits(bt * 16, ins) | gl;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) nxt[i] = NT ? ld_nt(amp + (base | lay.goff_i[i])) : amp[base | lay.goff_i[i]];
+  }
+  while (bt < nbatch) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<cplx*>(pm + lay.loff_i[i]) = nxt[i];
+    const uint64_t cur = base;
+    bt += nwaves;
+    if (bt < nbatch) {
+      base = ins_bits(bt * 16, ins) | gl;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) nxt[i] = NT ? ld_nt(amp + (base | lay.goff_i[i])) : amp[base | lay.goff_i[i]];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    cplx v[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) v[ks] = *reinterpret_cast<const cplx*>(po + ks * 4 * RS);
+    int lofs = lane;
+    asm volatile("" : "+v"(lofs));                          // re-read the fragments every batch (hoisted they are 96 VGPRs)
+    f64x4 t1[MB], t2[MB], t3[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      t1[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      t2[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+      t3[mb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const double bre = v[ks].x, dif = v[ks].y - v[ks].x, sum = v[ks].x + v[ks].y;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lofs;
+        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], bre, t1[mb], 0, 0, 0);
+        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[64], dif, t2[mb], 0, 0, 0);
+        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[128], sum, t3[mb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // results into the image (D row = 16 mb + 4 r + kq), then out by the map they came in by
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<cplx*>(po + (mb * 16 + 4 * r) * RS) = make_double2(t1[mb][r] - t3[mb][r], t1[mb][r] + t2[mb][r]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const cplx o = *reinterpret_cast<const cplx*>(pm + lay.loff_i[i]);
+      if (NT) st_nt(amp + (cur | lay.goff_i[i]), o); else amp[cur | lay.goff_i[i]] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_kq_tile<K>: dense 2^K x 2^K (K <= 3) on the vector units, one thread per group of 2^K amplitudes
 // in registers, one group per thread and no grid-stride loop (the stream shape of every other sweep here),
 // matrix rows read from LDS as broadcasts.  8 * 2^K flop per 32 B is 2 flop/B at K = 3: a quarter of

@@ -19,7 +19,7 @@ if pmc:
 for name, qs in cases:
     u = ru(len(qs))
     line = "%-10s" % name
-    for variant, tile3, bpc, ch in ((0, 0, 0, 0), (3, 0, 0, 0), (5, 0, 0, 0), (5, 0, 16, 0), (5, 0, 32, 0), (5, 0, 128, 0), (3, 2, 0, 0)):
+    for variant, tile3, bpc, ch in ((0, 0, 0, 0), (3, 0, 0, 0), (5, 0, 0, 0), (6, 0, 0, 0), (6, 0, 2, 0), (6, 0, 4, 0), (6, 0, 32, 0), (3, 2, 0, 0)):
         if (tile3 and len(qs) != 3) or (pmc and (bpc or ch or variant in (0, 2))):
             continue
         eng.set_option("kq_variant", variant)
