@@ -1054,7 +1054,7 @@ struct KqLds {
   uint32_t loff_i[8];            // ... and of the byte offset in the image (row * 272 + column * 16)
   uint32_t lane_loff[6];
 };
-template <int K, bool NT, int NW>
+template <int K, bool NT, int NW, int DBG = 0, int PD = 1>  // DBG (measurement only): 1 no matrix products, 2 no global memory traffic; PD: batches of loads in flight per wave
 __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint64_t nbatch, BitIns ins, KqLds lay,
                                                     const double* __restrict__ ur, const double* __restrict__ ui) {
   constexpr int D = 1 << K, MB = D / 16, KS = D / 4, NI = D / 4, RS = QSV_KQ_LDS_RS;
@@ -1083,24 +1083,29 @@ __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint
   char* po = image + kq * RS + (lane & 15) * 16;            // operand order: row kq of a slice, column lane & 15
   const uint64_t wave0 = (uint64_t)blockIdx.x * NW + (threadIdx.x >> 6);
   const uint64_t nwaves = (uint64_t)gridDim.x * NW;
-  uint64_t bt = wave0;
-  uint64_t base = 0;
-  cplx nxt[NI];
-  if (bt < nbatch) {
-    base = ins_bits(bt * 16, ins) | gl;
+  if (wave0 >= nbatch) return;                              // (no workgroup barrier below)
+  // This wave's batches: wave0 + k nwaves, k < n_my.  gfx950 counts loads and stores in ONE in-order counter (vmcnt) and
+  // hipcc takes the most cautious of the states that meet at a loop head: a prefetch that is skipped on some path, or a
+  // first iteration that enters with fewer operations pending than the back edge brings, turns every wait in the loop
+  // into "everything issued so far" -- the wave then sits out the latency of its own stores once per batch (what held
+  // every grid-stride form of this gate at 0.64-0.71).  So: every fetch is unconditional (past the last batch the index
+  // clamps to it: a re-read nobody uses), and the first round is peeled, so that both ways into the loop carry the same
+  // pending operations.
+  const uint64_t n_my = (nbatch - wave0 + nwaves - 1) / nwaves;
+  uint64_t bases[PD];
+  cplx nxt[PD][NI];
+  auto fetch = [&](int p, uint64_t k) __attribute__((always_inline)) {
+    const uint64_t kk = k < n_my ? k : n_my - 1;
+    bases[p] = ins_bits((wave0 + kk * nwaves) * 16, ins) | gl;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) nxt[i] = NT ? ld_nt(amp + (base | lay.goff_i[i])) : amp[base | lay.goff_i[i]];
-  }
-  while (bt < nbatch) {
+    for (int i = 0; i < NI; ++i)
+      nxt[p][i] = DBG == 2 ? make_double2((double)(bases[p] + i), 1.0) : NT ? ld_nt(amp + (bases[p] | lay.goff_i[i])) : amp[bases[p] | lay.goff_i[i]];
+  };
+  auto step = [&](int p, uint64_t k, bool refill) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<cplx*>(pm + lay.loff_i[i]) = nxt[i];
-    const uint64_t cur = base;
-    bt += nwaves;
-    if (bt < nbatch) {
-      base = ins_bits(bt * 16, ins) | gl;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) nxt[i] = NT ? ld_nt(amp + (base | lay.goff_i[i])) : amp[base | lay.goff_i[i]];
-    }
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<cplx*>(pm + lay.loff_i[i]) = nxt[p][i];
+    const uint64_t cur = bases[p];
+    if (refill) fetch(p, k + PD);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1121,10 +1126,11 @@ __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint
       const double bre = v[ks].x, dif = v[ks].y - v[ks].x, sum = v[ks].x + v[ks].y;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const double* p = lds_a + ((mb * KS + ks) * 3) * 64 + lofs;
-        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], bre, t1[mb], 0, 0, 0);
-        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[64], dif, t2[mb], 0, 0, 0);
-        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[128], sum, t3[mb], 0, 0, 0);
+        const double* pa = lds_a + ((mb * KS + ks) * 3) * 64 + lofs;
+        if (DBG == 1) { t1[mb][ks & 3] += bre; t2[mb][ks & 3] += dif; t3[mb][ks & 3] += sum * pa[0]; continue; }
+        t1[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], bre, t1[mb], 0, 0, 0);
+        t2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[64], dif, t2[mb], 0, 0, 0);
+        t3[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[128], sum, t3[mb], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1140,11 +1146,28 @@ __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const cplx o = *reinterpret_cast<const cplx*>(pm + lay.loff_i[i]);
+      if (DBG == 2) { if (o.x == 0.12345) amp[cur | lay.goff_i[i]] = o; continue; }
       if (NT) st_nt(amp + (cur | lay.goff_i[i]), o); else amp[cur | lay.goff_i[i]] = o;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+#pragma unroll
+  for (int p = 0; p < PD; ++p) fetch(p, p);
+  uint64_t k0 = 0;
+  if (n_my >= PD) {                                         // the peeled round
+#pragma unroll
+    for (int p = 0; p < PD; ++p) step(p, p, true);
+    for (k0 = PD; k0 + PD <= n_my; k0 += PD) {
+#pragma unroll
+      for (int p = 0; p < PD; ++p) step(p, k0 + p, true);
+    }
+  }
+  if (PD > 1) {                                             // fewer than PD batches left: they sit in the slots already
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+      if (k0 + p < n_my) step(p, k0 + p, false);
   }
 }
 

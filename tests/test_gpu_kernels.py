@@ -167,11 +167,11 @@ def test_kq_dense(lib, n, k, mfma):
 
 
 @pytest.mark.parametrize("variant,tile3,nt,chunked", [(0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 1, 0, 0), (1, 2, 1, 0), (2, 0, 1, 1),
-                                                    (2, 2, 1, 0), (3, 0, 0, 0), (3, 1, 1, 1), (4, 0, 0, 0), (4, 0, 1, 0), (5, 0, 0, 0), (5, 1, 1, 0), (6, 0, 0, 0), (6, 0, 1, 0)])
+                                                    (2, 2, 1, 0), (3, 0, 0, 0), (3, 1, 1, 1), (4, 0, 0, 0), (4, 0, 1, 0), (5, 0, 0, 0), (5, 1, 1, 0), (6, 0, 0, 0), (6, 0, 1, 0), (7, 0, 0, 0), (8, 0, 1, 0)])
 @pytest.mark.parametrize("n,k", [(9, 3), (14, 3), (12, 4), (13, 5), (16, 5)])
 def test_kq_kernel_variants(lib, n, k, variant, tile3, nt, chunked):
     """every form of the dense k-qubit gate: four real matrix-core products per complex one (0), three (Gauss, 1), three
-    with the next batch prefetched (2), the A fragments in LDS (3 with, 4 without prefetch), two batches per step loaded 32 groups wide with lane swaps (5), the batch staged through LDS and moved in memory order (6); K = 3 on the vector units
+    with the next batch prefetched (2), the A fragments in LDS (3 with, 4 without prefetch), two batches per step loaded 32 groups wide with lane swaps (5), the batch staged through LDS and moved in memory order (6; 7, 8: two, three batches of loads in flight per wave); K = 3 on the vector units
     (k_kq_tile: 1 when no target sits inside a 128-byte line, 2 always) or embedded in a 16 x 16 matrix-core tile; plain and non-temporal / index-swizzled access; grid-stride and contiguous walks -- against numpy"""
     rs = np.random.RandomState(n * 31 + k)
     ref = rand_state(n, 23)
