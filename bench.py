@@ -665,6 +665,13 @@ def main():
         if args.gpus == 1 and not args.no_cpu:
             backend.close()
             line["cpu_baseline"] = cpu_baseline(cliques, theta, args.shots, args.cpu_seconds)
+            # the port executes the UNFUSED reference-order stream: the GPU number that does the same work is the
+            # fusion-0 variant, not `value` (which runs the circuit fused into one write pass)
+            like = variants.get("unfused reference-order gate stream (fusion=0)")
+            if isinstance(like, dict) and "shots_per_s" in like and line["cpu_baseline"].get("value"):
+                line["cpu_baseline"]["like_for_like"] = {
+                    "gpu_variant": "unfused reference-order gate stream (fusion=0)", "gpu_shots_per_s": like["shots_per_s"],
+                    "gpu_over_cpu": like["shots_per_s"] / line["cpu_baseline"]["value"]}
         print(json.dumps(line), flush=True)
     backend.close()
     if world > 1:

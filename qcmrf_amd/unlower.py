@@ -224,6 +224,12 @@ def _cls_of(op):
 
 OK, BOUNDARY, STUCK, BARRIER = 0, 1, 2, 3
 _OVERFLOW = [False]                     # a window ran out of variables during the current run
+_GIVE_UP = [False]                      # ... and the run is to stop right there (the wider windows take over)
+
+
+class _Overflow(Exception):
+    """a window of 8 variables ran out of room"""
+
 
 
 class _Frame:
@@ -729,6 +735,8 @@ class _Window:
             if len(self.free) >= need:
                 return True
         _OVERFLOW[0] = True
+        if _GIVE_UP[0]:
+            raise _Overflow()
         return False
 
     def flush(self, out):
@@ -750,20 +758,32 @@ class _Window:
 _LOCK = threading.Lock()
 
 
+_WIDE = {}                                                # programs (by length and first gates) that needed windows of 10 variables
+
+
 def unlower(ops):
-    """see ``_run``; windows of 8 variables first, of 10 if those ran out of room and left raw gates behind"""
+    """see ``_run``; windows of 8 variables first; the moment one of them runs out of room the run is dropped and
+    windows of 10 take over (what they cannot hold either goes out raw).  A program that needed the wide windows is
+    remembered by its shape (length, opening gates): the next one like it -- the reference runs ten circuits per graph,
+    `run_experiment.py:44-47` -- starts with them.  (Both widths are exact; this only decides which is tried first.)"""
+    key = (len(ops), tuple((o if o[0] in "cx" else o[0]) if type(o) is tuple else o.kind for o in ops[:24]))
     with _LOCK:
-        _OVERFLOW[0] = False
-        out, n_raw = _run(ops)
-        if n_raw and _OVERFLOW[0]:
-            _configure(10)
+        if not _WIDE.get(key):
+            _OVERFLOW[0] = False
+            _GIVE_UP[0] = True
             try:
-                out2, n_raw2 = _run(ops)
+                return _run(ops)
+            except _Overflow:
+                if len(_WIDE) > 256:
+                    _WIDE.clear()
+                _WIDE[key] = True
             finally:
-                _configure(8)
-            if n_raw2 < n_raw:
-                out, n_raw = out2, n_raw2
-        return out, n_raw
+                _GIVE_UP[0] = False
+        _configure(10)
+        try:
+            return _run(ops)
+        finally:
+            _configure(8)
 
 
 def _run(ops):
