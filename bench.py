@@ -74,7 +74,7 @@ def parse():
                     help="fold_fresh off: every fused gate is applied as a sweep of the full vector (k_multi passes)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=int")
     ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the reference-layout legs (RCCL / peer-mapped shard-bit exchanges)")
-    ap.add_argument("--exchange-deadline", type=float, default=240.0, help="seconds one exchange leg may take before it is abandoned")
+    ap.add_argument("--exchange-deadline", type=float, default=150.0, help="seconds one exchange leg may take before it is abandoned")
     ap.add_argument("--exchange-child", action="store_true", help=argparse.SUPPRESS)   # internal: run only the exchange legs, print their JSON
     return ap.parse_args()
 
