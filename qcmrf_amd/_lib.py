@@ -26,7 +26,7 @@ K_COUNT = len(K_NAMES)
 OPTION_DEFAULTS = {"blocks_per_cu": 1 << 16, "unroll": 4, "lowt_shuffle": 1, "nontemporal": -1, "lane_targets": 1,
                    "cache_sums": 1, "fused_sums": 1, "pair_variant": 0, "kq_mfma": 1, "zero_tracking": 0, "lane_map": 1,
                    "init_prod_bit0": 0, "init_prod_r": 0, "init_prod": 1, "pass_hints": 1, "dyn_lanes": 3, "multi_r": 5,
-                   "exchange_chunk_log2": 24, "xframe": 1, "pass_budget": 0, "trace_passes": 0, "single_shortcut": 1, "pass_max_ops": 56, "general_r": 4, "general_light_r": 5, "swizzle": 1, "lane_map_min_l": 26, "blocksum_variant": 6, "kq_chunked": 0, "fold_init_h": 1, "general_combos": 1, "lowctl_mask": 1, "kq_variant": -1, "kq3_tile": 1, "kq_blocks_per_cu": 0, "kq_debug": 0, "multi_nt": -1, "init_prod_nt": -1}
+                   "exchange_chunk_log2": 24, "xframe": 1, "pass_budget": 0, "trace_passes": 0, "single_shortcut": 1, "pass_max_ops": 56, "general_r": 4, "general_light_r": 5, "swizzle": 1, "lane_map_min_l": 26, "blocksum_variant": 6, "kq_chunked": 0, "fold_init_h": 1, "general_combos": 1, "lowctl_mask": 1, "kq_variant": -1, "kq3_tile": 1, "kq_blocks_per_cu": 0, "kq_debug": 0, "kq_order": 1, "multi_nt": -1, "init_prod_nt": -1}
 
 OP_INIT_ZERO, OP_INIT_UNIFORM, OP_1Q, OP_MCX, OP_DIAG, OP_MCPHASE, OP_MUX, OP_KQ, OP_SWAP = range(9)
 OPF_NEW_PASS = 1

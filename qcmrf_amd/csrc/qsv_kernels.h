@@ -1053,7 +1053,8 @@ struct KqLds {
   uint64_t lane_goff[6];         // lane bit n: its part of the amplitude index
   uint32_t loff_i[8];            // ... and of the byte offset in the image (row * 272 + column * 16)
   uint32_t lane_loff[6];
-};
+  int swap_lo;                   // >= 0: lane bit 5 stands for address bit 11 (two 512-byte runs 32 KiB apart per wave access,
+};                               //       DESIGN.md 3b); the batch number's bit 11 moves to this group-bit position instead
 template <int K, bool NT, int NW, int DBG = 0, int PD = 1>  // DBG (measurement only): 1 no matrix products, 2 no global memory traffic; PD: batches of loads in flight per wave
 __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint64_t nbatch, BitIns ins, KqLds lay,
                                                     const double* __restrict__ ur, const double* __restrict__ ui) {
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint
   const int lane = threadIdx.x & 63;
   const int kq = lane >> 4;
   extern __shared__ double lds_a[];                        // [mb][ks][3][64 lanes]: (Ur + Ui), Ur, Ui fragments; then NW images
-  if (threadIdx.x < 64) {
+  if (DBG != 3 && threadIdx.x < 64) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1096,12 +1097,24 @@ __global__ __launch_bounds__(NW * 64) void k_kq_lds(cplx* __restrict__ amp, uint
   cplx nxt[PD][NI];
   auto fetch = [&](int p, uint64_t k) __attribute__((always_inline)) {
     const uint64_t kk = k < n_my ? k : n_my - 1;
-    bases[p] = ins_bits((wave0 + kk * nwaves) * 16, ins) | gl;
+    uint64_t b = ins_bits((wave0 + kk * nwaves) * 16, ins);
+    if (lay.swap_lo >= 0) b = (b & ~(1ull << 11)) | (((b >> 11) & 1) << lay.swap_lo);
+    bases[p] = b | gl;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       nxt[p][i] = DBG == 2 ? make_double2((double)(bases[p] + i), 1.0) : NT ? ld_nt(amp + (bases[p] | lay.goff_i[i])) : amp[bases[p] | lay.goff_i[i]];
   };
   auto step = [&](int p, uint64_t k, bool refill) __attribute__((always_inline)) {
+    if (DBG == 3) {                                         // (measurement only: the loop as a plain copy, no LDS, no products)
+      cplx keep[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) keep[i] = nxt[p][i];
+      const uint64_t cur3 = bases[p];
+      if (refill) fetch(p, k + PD);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) { keep[i].x += 1.0; st_nt(amp + (cur3 | lay.goff_i[i]), keep[i]); }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<cplx*>(pm + lay.loff_i[i]) = nxt[p][i];
     const uint64_t cur = bases[p];

@@ -19,13 +19,14 @@ if pmc:
 for name, qs in cases:
     u = ru(len(qs))
     line = "%-10s" % name
-    for variant, tile3, bpc, ch in ((3, 0, 0, 0), (5, 0, 0, 0), (6, 0, 0, 0), (6, 0, 0, -1), (7, 0, 0, 0), (7, 0, 0, -1), (8, 0, 0, 0), (8, 0, 0, -1), (8, 0, 2, 0), (3, 2, 0, 0)):
+    for variant, tile3, bpc, ch in ((3, 0, 0, 0), (3, 0, 0, 10), (3, 0, 0, 20), (3, 0, 0, 30), (5, 0, 0, 0), (5, 0, 0, 10), (5, 0, 0, 20), (5, 0, 0, 30), (8, 0, 0, 0), (8, 0, 2, 0), (8, 0, 4, 0), (3, 2, 0, 0)):
         if (tile3 and len(qs) != 3) or (pmc and (bpc or ch or variant in (0, 2))):
             continue
         eng.set_option("kq_variant", variant)
         eng.set_option("kq3_tile", tile3)
         eng.set_option("kq_blocks_per_cu", bpc)
-        eng.set_option("kq_chunked", max(ch, 0))
+        eng.set_option("kq_order", ch // 10 if ch >= 10 else 0)     # (10, 20, 30: kq_order 1, 2, 3)
+        eng.set_option("kq_chunked", ch if 0 < ch < 10 else 0)
         eng.set_option("kq_debug", -ch if ch < 0 else 0)        # (v6 only: c-1 = no products, c-2 = no memory traffic; results are garbage)
         reps = 2 if pmc else 8
         for _ in range(0 if pmc else 2): eng.apply_kq(qs, u)

@@ -184,7 +184,32 @@ def test_kq_kernel_variants(lib, n, k, variant, tile3, nt, chunked):
         e.set_amplitudes(0, ref)
         for trial in range(5):
             qs = rs.permutation(n)[:k].tolist() if trial else list(range(k))       # incl. the k lowest bits
+            if trial == 4 and n > 11 and 11 not in qs:
+                qs[-1] = 11                                # a target on address bit 11: it becomes index bit 0 (kq_order 1)
             u = rand_u(k, 40 + trial)
+            e.apply_kq(qs, u)
+            sv.apply_kq(ref, qs, u)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("order", [0, 2, 3, 4])
+@pytest.mark.parametrize("variant", [3, 5, 8])
+@pytest.mark.parametrize("n,k", [(14, 3), (13, 4), (16, 5)])
+def test_kq_target_order_is_the_kernels_choice(lib, n, k, variant, order):
+    """which target is index bit 0, 1, ... of the matrix is an access-pattern choice of the matrix-core kernels (kq_order:
+    as given / ascending / descending / nearest address bit 11 first; the default, a target on bit 11 first, runs in every other test): the matrix is re-indexed to match, the gate is the same"""
+    rs = np.random.RandomState(n * 7 + k + order)
+    ref = rand_state(n, 29)
+    with lib.Engine(n) as e:
+        e.set_option("kq_variant", variant)
+        e.set_option("kq3_tile", 0)
+        e.set_option("kq_order", order)
+        e.set_amplitudes(0, ref)
+        for trial in range(4):
+            qs = rs.permutation(n)[:k].tolist()
+            if trial == 3:
+                qs[1] = 11 if 11 not in qs else qs[1]             # a target on bit 11 somewhere in the middle
+            u = rand_u(k, 60 + trial)
             e.apply_kq(qs, u)
             sv.apply_kq(ref, qs, u)
         assert np.abs(e.amplitudes() - ref).max() < 1e-12
