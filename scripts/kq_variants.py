@@ -19,7 +19,7 @@ if pmc:
 for name, qs in cases:
     u = ru(len(qs))
     line = "%-10s" % name
-    for variant, tile3, bpc, ch in ((3, 0, 0, 0), (3, 0, 0, 10), (3, 0, 0, 20), (3, 0, 0, 30), (5, 0, 0, 0), (5, 0, 0, 10), (5, 0, 0, 20), (5, 0, 0, 30), (8, 0, 0, 0), (8, 0, 2, 0), (8, 0, 4, 0), (3, 2, 0, 0)):
+    for variant, tile3, bpc, ch in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0), (5, 0, 0, 0), (8, 0, 0, 0), (3, 2, 0, 0)):
         if (tile3 and len(qs) != 3) or (pmc and (bpc or ch or variant in (0, 2))):
             continue
         eng.set_option("kq_variant", variant)
