@@ -2,6 +2,7 @@
 operand-layout kernel (kq_variant 3), the LDS-staged one (6), the LDS-staged one without its products (kq_debug 1), and for
 comparison a plain read+write stream of the same bytes (a dense one-qubit gate on bit 20).  Three launches each."""
 import os, sys
+os.environ.setdefault("QSV_MEASUREMENT_KNOBS", "1")         # kq_debug: kernels with a part of their work left out (timing only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qcmrf_amd import _lib

@@ -1,7 +1,8 @@
 """GPU box: dense k-qubit gates (k_kq_mfma / k_kq_mfma3 / k_kq_tile): every kq_variant on the micro-benchmark's cases.
    python scripts/kq_variants.py        timing table
    python scripts/kq_variants.py pmc    two launches per (case, variant), for rocprofv3 --pmc"""
-import sys, os
+import os, sys
+os.environ.setdefault("QSV_MEASUREMENT_KNOBS", "1")         # kq_debug: kernels with a part of their work left out (timing only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from qcmrf_amd import _lib

@@ -215,6 +215,16 @@ def test_kq_target_order_is_the_kernels_choice(lib, n, k, variant, order):
         assert np.abs(e.amplitudes() - ref).max() < 1e-12
 
 
+def test_measurement_knob_needs_the_opt_in(lib, monkeypatch):
+    """kq_debug times the LDS-staged dense-gate kernel with a part of its work left out (scripts/kq_variants.py): the
+    state it leaves is wrong by design, so the library takes it only with QSV_MEASUREMENT_KNOBS in the environment"""
+    monkeypatch.delenv("QSV_MEASUREMENT_KNOBS", raising=False)
+    with lib.Engine(10) as e:
+        with pytest.raises(ValueError, match="QSV_MEASUREMENT_KNOBS"):
+            e.set_option("kq_debug", 1)
+        e.set_option("kq_debug", 0)
+
+
 def test_nontemporal_kernel_forms(lib):
     """every one-gate kernel in its non-temporal form (loads and stores that bypass the caches: what
     states of >= 2^26 amplitudes select by themselves) against the numpy oracle at a size where the
