@@ -156,6 +156,8 @@ struct Shard {
   double* d_sres = nullptr;
   uint64_t* d_sout = nullptr;
   size_t sample_cap = 0;
+  double* d_red = nullptr;       // scratch of the reductions (marginals, expectation partial sums): grown on demand, kept
+  size_t red_cap = 0;            // ... in doubles
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
 };
@@ -391,6 +393,7 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.xstream) { hipStreamSynchronize(s.xstream); hipStreamDestroy(s.xstream); }
     if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
     if (s.d_tsums) hipFree(s.d_tsums);
+    if (s.d_red) hipFree(s.d_red);
     if (s.h_tsums) hipHostFree(s.h_tsums);
     if (s.d_super) hipFree(s.d_super);
     if (s.stream) hipStreamDestroy(s.stream);

@@ -9,8 +9,9 @@ measurement outcomes: the engine walks the tree of outcomes depth first, splitti
 every measurement by a binomial draw from the exact branch probability, and only visits branches
 that still hold shots.  Everything on the device is the same hand-written HIP path (the segments
 between measurements are compiled by the same exact fusion passes and run through ``qsv_exec``;
-the branch probability is ``qsv_probabilities``, the collapse a one-qubit diagonal, the branch
-point ``qsv_copy_state``).  No closed-form knowledge of the circuit is used.
+the branch probability is ``qsv_probabilities``, the collapse a one-qubit 0/1 diagonal that rides in
+front of the child segment's program -- one pass, the state stays unnormalised -- the branch point
+``qsv_copy_state``).  No closed-form knowledge of the circuit is used.
 """
 from __future__ import annotations
 
@@ -22,7 +23,9 @@ from . import _lib, ingest as _ingest, ir, passes, planner, program
 
 
 class _Segment:
-    __slots__ = ("rec", "data", "n_ops", "measure_slot", "measure_clbit", "release")
+    # prog[outcome]: this segment's program behind the projection of the PREVIOUS segment's measurement on ``outcome``
+    # (and the X that hands a released slot back in |0>), in one record list: one pass over the state instead of three
+    __slots__ = ("rec", "data", "n_ops", "measure_slot", "measure_clbit", "release", "prog")
 
 
 def _live_plan(ops, n_qubits):
@@ -104,6 +107,17 @@ def compile_trajectory(circuit, fusion=3):
         sg.n_ops = len(fused)
         sg.measure_slot = sg.measure_clbit = None
         sg.release = False
+        sg.prog = None
+        if segs:
+            # the state stays UNNORMALISED along a branch (the projection is the 0/1 table, not 1/sqrt(p)): branch
+            # probabilities are ratios and the sampler divides by the mass it finds
+            prev = segs[-1]
+            sg.prog = {}
+            for outcome in (0, 1):
+                pre = [ir.op_diag([prev.measure_slot], [1.0 - outcome, float(outcome)])]
+                if outcome == 1 and prev.release:
+                    pre.append(ir.op_x(prev.measure_slot))
+                sg.prog[outcome] = program.encode(pre + list(fused))
         if i + 1 < len(staged):
             _, s, c, rel = staged[i + 1]
             sg.measure_slot, sg.measure_clbit, sg.release = s, c, rel
@@ -135,12 +149,13 @@ def run_trajectories(circuit, shots, seed, fusion=3, device=0, engine_factory=No
     stats = {"nodes": 0, "copies": 0, "sweeps": 0}
     fm_slots = [s for s, _ in final_measures]
 
-    def node(level, eng, k, bits):
+    def node(level, eng, k, bits, came_by):
         sg = segs[level]
         stats["nodes"] += 1
         stats["sweeps"] += sg.n_ops
-        if len(sg.rec):
-            eng.exec(sg.rec, sg.data)
+        rec, data = (sg.rec, sg.data) if came_by is None else sg.prog[came_by]
+        if len(rec):
+            eng.exec(rec, data)
         if sg.measure_slot is None:                         # leaf: joint sample of what is left
             if fm_slots:
                 smp = eng.sample(k, int(rng.randint(0, 2 ** 31 - 1)), fm_slots)
@@ -163,20 +178,15 @@ def run_trajectories(circuit, shots, seed, fusion=3, device=0, engine_factory=No
             other = get_engine()
             other.copy_from(eng)
             stats["copies"] += 1
+        # the projection on the outcome (and the X that hands a released slot back) ride in front of the child's program
         for outcome, kk, e in ((0, k0, eng), (1, k1, other if other is not None else eng)):
-            if kk == 0:
-                continue
-            tab = np.zeros(2, dtype=np.complex128)
-            tab[outcome] = 1.0 / np.sqrt(p[outcome])
-            e.apply_diag([sg.measure_slot], tab)            # project + renormalise
-            if outcome == 1 and sg.release:
-                e.apply_mcx([], sg.measure_slot)            # hand the slot back in |0>
-            node(level + 1, e, kk, bits | (outcome << sg.measure_clbit))
+            if kk:
+                node(level + 1, e, kk, bits | (outcome << sg.measure_clbit), outcome)
         if other is not None:
             pool.append(other)
 
     root = get_engine()
-    node(0, root, int(shots), 0)
+    node(0, root, int(shots), 0, None)
     t2 = time.perf_counter()
     for e in created:
         e.close()
