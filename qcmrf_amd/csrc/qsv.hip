@@ -156,6 +156,7 @@ struct Shard {
   double* d_sres = nullptr;
   uint64_t* d_sout = nullptr;
   size_t sample_cap = 0;
+  hipEvent_t ev_copied = nullptr; // qsv_copy_state: this shard has been read completely (the source's stream waits for it)
   double* d_red = nullptr;       // scratch of the reductions (marginals, expectation partial sums): grown on demand, kept
   size_t red_cap = 0;            // ... in doubles
   std::vector<Pending> pending;
@@ -394,6 +395,7 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.d_sblk) { hipFree(s.d_sblk); hipFree(s.d_sres); hipFree(s.d_sout); }
     if (s.d_tsums) hipFree(s.d_tsums);
     if (s.d_red) hipFree(s.d_red);
+    if (s.ev_copied) hipEventDestroy(s.ev_copied);
     if (s.h_tsums) hipHostFree(s.h_tsums);
     if (s.d_super) hipFree(s.d_super);
     if (s.stream) hipStreamDestroy(s.stream);

@@ -22,6 +22,9 @@ import numpy as np
 from . import _lib, ingest as _ingest, ir, passes, planner, program
 
 
+_ONE = np.array([0.0, 1.0])                               # the observable |1><1| of a measured slot
+
+
 class _Segment:
     # prog[outcome]: this segment's program behind the projection of the PREVIOUS segment's measurement on ``outcome``
     # (and the X that hands a released slot back in |0>), in one record list: one pass over the state instead of three
@@ -169,9 +172,10 @@ def run_trajectories(circuit, shots, seed, fusion=3, device=0, engine_factory=No
                 out_vals.append(bits)
                 out_cnts.append(k)
             return
-        p = eng.probabilities([sg.measure_slot])
-        tot = p[0] + p[1]
-        k1 = int(rng.binomial(k, min(max(p[1] / tot, 0.0), 1.0))) if tot > 0 else 0
+        # mass on outcome 1 and total mass in one read pass with a FIXED summation order (qsv_expect_diag: per-workgroup
+        # partial sums, no atomics): the same seed walks the same tree on every run
+        p1, tot = eng.expect_diag([sg.measure_slot], _ONE)
+        k1 = int(rng.binomial(k, min(max(p1 / tot, 0.0), 1.0))) if tot > 0 else 0
         k0 = k - k1
         other = None
         if k0 > 0 and k1 > 0:

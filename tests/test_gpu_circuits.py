@@ -436,6 +436,21 @@ def test_trajectory_mode_small_and_beyond_statevector_reach(be, models):
     tb.close()
 
 
+def test_trajectory_mode_is_reproducible_for_a_seed():
+    """branch probabilities are summed in a fixed order (no atomics): the same seed_simulator walks the same tree of
+    outcomes and returns the same counts, run after run (BASELINE seeds the sampler: seed_simulator=1984)"""
+    from qcmrf_amd import QCMRF, workloads
+    from qcmrf_amd.backend import QsvBackend
+    tb = QsvBackend(method="trajectory")
+    C = workloads.chain(14)
+    qc = QCMRF(C, workloads.theta_halfnorm(workloads.dimension(C), scale=0.25))
+    runs = [tb.run(qc, shots=2048, seed_simulator=1984).result() for _ in range(3)]
+    assert runs[0].get_counts() == runs[1].get_counts() == runs[2].get_counts()
+    assert len({r.metadata(0)["branch_nodes"] for r in runs}) == 1
+    assert tb.run(qc, shots=2048, seed_simulator=7).result().get_counts() != runs[0].get_counts()
+    tb.close()
+
+
 @pytest.mark.parametrize("fusion", [0, 3])
 def test_random_circuit_w20_against_c_oracle(be, fusion):
     """a 20-qubit random circuit (all gate kinds, targets on lane / register / block bits) against

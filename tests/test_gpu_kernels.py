@@ -215,6 +215,31 @@ def test_kq_target_order_is_the_kernels_choice(lib, n, k, variant, order):
         assert np.abs(e.amplitudes() - ref).max() < 1e-12
 
 
+def test_copy_state_has_read_the_source_before_the_source_moves_on(lib):
+    """qsv_copy_state runs on the destination's stream; the source's next kernels (a trajectory run projects it on the
+    sibling outcome at once) wait for it -- without that wait the copy of a 1 GiB state picked up amplitudes the
+    projection had already zeroed, and a seeded trajectory run walked a different tree every time"""
+    n = 26
+    with lib.Engine(n) as a, lib.Engine(n) as b:
+        a.init_uniform((1 << n) - 1)
+        a.apply_diag([0, n - 1], np.exp(1j * np.arange(4)))
+        a.sync()
+        windows = [0, (1 << (n - 1)) - 2048, (1 << (n - 1)), (1 << n) - 4096]
+        want = [a.amplitudes(w, 4096) for w in windows]
+        for rep in range(4):
+            b.copy_from(a)
+            a.apply_diag([n - 1], np.array([0.0, 1.0]))       # zeroes the first half of the source at once
+            a.apply_mcx([], n - 1)
+            got = [b.amplitudes(w, 4096) for w in windows]
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w), rep
+            a.copy_from(b)                                    # ... and back, the same way round
+            b.apply_diag([n - 1], np.array([1.0, 0.0]))
+            got = [a.amplitudes(w, 4096) for w in windows]
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w), rep
+
+
 def test_measurement_knob_needs_the_opt_in(lib, monkeypatch):
     """kq_debug times the LDS-staged dense-gate kernel with a part of its work left out (scripts/kq_variants.py): the
     state it leaves is wrong by design, so the library takes it only with QSV_MEASUREMENT_KNOBS in the environment"""
