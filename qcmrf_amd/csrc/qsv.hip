@@ -156,7 +156,8 @@ struct Shard {
   double* d_sres = nullptr;
   uint64_t* d_sout = nullptr;
   size_t sample_cap = 0;
-  hipEvent_t ev_copied = nullptr; // qsv_copy_state: this shard has been read completely (the source's stream waits for it)
+  hipEvent_t ev_ready = nullptr;  // qsv_copy_state: everything asked of this shard so far has run (the destination's stream waits for it)
+  hipEvent_t ev_copied = nullptr; // ... and this shard has been read completely (its own stream waits for that)
   double* d_red = nullptr;       // scratch of the reductions (marginals, expectation partial sums): grown on demand, kept
   size_t red_cap = 0;            // ... in doubles
   std::vector<Pending> pending;
@@ -396,6 +397,7 @@ extern "C" int qsv_destroy(qsv_handle* h) {
     if (s.d_tsums) hipFree(s.d_tsums);
     if (s.d_red) hipFree(s.d_red);
     if (s.ev_copied) hipEventDestroy(s.ev_copied);
+    if (s.ev_ready) hipEventDestroy(s.ev_ready);
     if (s.h_tsums) hipHostFree(s.h_tsums);
     if (s.d_super) hipFree(s.d_super);
     if (s.stream) hipStreamDestroy(s.stream);
