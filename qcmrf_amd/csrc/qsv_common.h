@@ -46,6 +46,12 @@ __host__ __device__ __forceinline__ uint64_t swz_5_11(uint64_t i) {
   const uint64_t d = ((i >> 5) ^ (i >> 11)) & 1ull;
   return i ^ (d << 5) ^ (d << 11);
 }
+// ... and with the partner of bit 11 chosen by the host: the address bit lane bit 5 of an enumeration lands on (bit 5
+// itself unless the gate's controls / target take it: then the next free one)
+__host__ __device__ __forceinline__ uint64_t swz_a_11(uint64_t i, int a) {
+  const uint64_t d = ((i >> a) ^ (i >> 11)) & 1ull;
+  return i ^ (d << a) ^ (d << 11);
+}
 __device__ __forceinline__ uint32_t gather_bits(uint64_t x, const BitList& b) {
   uint32_t j = 0;
   for (int k = 0; k < b.n; ++k) j |= (uint32_t)((x >> b.pos[k]) & 1ull) << k;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
       if (!GUARD || p < npairs) {
         i0[u] = ins_bits(p, ins) | fixed;
-        if (swz) i0[u] = swz_5_11(i0[u]);
+        if (swz) i0[u] = swz_a_11(i0[u], swz);
         a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
         a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
       }
@@ -68,7 +68,9 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair(cplx* __restrict__ amp, uint64
 template <int KIND, int U, bool NT>
 __global__ __launch_bounds__(QSV_TPB) void k_pair_m(cplx* __restrict__ amp, uint64_t npairs,
                                                     BitIns ins, uint64_t fixed, uint64_t tbit,
-                                                    Mat2 m, uint64_t lmask, uint64_t lval) {
+                                                    Mat2 m, uint64_t lmask, uint64_t lval, int swa) {
+  // swa >= 0: address bits swa and 11 change places (both free: neither control nor target) -- swa is where lane bit 5
+  // of the enumeration lands, so a wave access becomes two 512-byte runs 32 KiB apart (swz_5_11 with a control on bit 5)
   const cplx m00 = make_double2(m.v[0], m.v[1]), m01 = make_double2(m.v[2], m.v[3]);
   const cplx m10 = make_double2(m.v[4], m.v[5]), m11 = make_double2(m.v[6], m.v[7]);
   const uint64_t base = (uint64_t)blockIdx.x * (QSV_TPB * U) + threadIdx.x;      // npairs % (QSV_TPB * U) == 0 (host)
@@ -77,6 +79,10 @@ __global__ __launch_bounds__(QSV_TPB) void k_pair_m(cplx* __restrict__ amp, uint
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     i0[u] = ins_bits(base + (uint64_t)u * QSV_TPB, ins) | fixed;
+    if (swa >= 0) {
+      const uint64_t d = ((i0[u] >> swa) ^ (i0[u] >> 11)) & 1ull;
+      i0[u] ^= (d << swa) ^ (d << 11);
+    }
     a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
     a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
   }
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_lowt(cplx* __restrict__ amp, uint64
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ix[u] = base + (uint64_t)u * QSV_TPB;
-      if (swz) ix[u] = swz_5_11(ix[u]);          // t < 5: lane bits 0..4 still are address bits 0..4
+      if (swz) ix[u] = swz_a_11(ix[u], swz);          // t < 5: lane bits 0..4 still are address bits 0..4
       a[u] = NT ? ld_nt(amp + ix[u]) : ld(amp + ix[u]);
     }
 #pragma unroll
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_mux(cplx* __restrict__ amp, uint64_
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
       if (!GUARD || p < npairs) {
         i0[u] = ((p >> t) << (t + 1)) | (p & lomask);
-        if (swz) i0[u] = swz_5_11(i0[u]);
+        if (swz) i0[u] = swz_a_11(i0[u], swz);
         a0[u] = NT ? ld_nt(amp + i0[u]) : ld(amp + i0[u]);
         a1[u] = NT ? ld_nt(amp + (i0[u] | tbit)) : ld(amp + (i0[u] | tbit));
       }
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_diag(cplx* __restrict__ amp, uint64
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       ix[u] = base + (uint64_t)u * QSV_TPB;
-      if (swz) ix[u] = swz_5_11(ix[u]);            // every amplitude is on its own: any bijection will do
+      if (swz) ix[u] = swz_a_11(ix[u], swz);            // every amplitude is on its own: any bijection will do
       if (!GUARD || ix[u] < n) a[u] = NT ? ld_nt(amp + ix[u]) : ld(amp + ix[u]);
     }
 #pragma unroll
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_mcphase(cplx* __restrict__ amp, uin
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t p = base + (uint64_t)u * QSV_TPB;
-      if (!GUARD || p < nsub) { idx[u] = ins_bits(p, ins) | fixed; if (swz) idx[u] = swz_5_11(idx[u]); a[u] = amp[idx[u]]; }
+      if (!GUARD || p < nsub) { idx[u] = ins_bits(p, ins) | fixed; if (swz) idx[u] = swz_a_11(idx[u], swz); a[u] = amp[idx[u]]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_swap_bits(cplx* __restrict__ amp, u
   const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
   for (uint64_t p = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; p < nq; p += stride) {
     uint64_t i = ins_bits(p, ins);
-    if (swz) i = swz_5_11(i);                              // neither swapped bit is bit 5 or 11 (host)
+    if (swz) i = swz_a_11(i, swz);                              // neither swapped bit is bit 5 or 11 (host)
     const cplx x = amp[i | abit], y = amp[i | bbit];
     amp[i | abit] = y;
     amp[i | bbit] = x;
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_swap_blocks(cplx* __restrict__ A, c
   const uint64_t stride = (uint64_t)gridDim.x * QSV_TPB;
   for (uint64_t q = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x; q < cnt; q += stride) {
     uint64_t i = ins_bits(p0 + q, ins);
-    if (swz) i = swz_5_11(i);       // a bijection of the block's index space (bits 5, 11 are not swapped bits): ranks that split [0, cnt) still split the block
+    if (swz) i = swz_a_11(i, swz);       // a bijection of the block's index space (bits 5, 11 are not swapped bits): ranks that split [0, cnt) still split the block
     const cplx x = A[i | fa], y = B[i | fb];
     A[i | fa] = y;
     B[i | fb] = x;
@@ -1203,7 +1209,7 @@ __global__ __launch_bounds__(QSV_TPB) void k_kq_tile(cplx* __restrict__ amp, uin
   const uint64_t g = (uint64_t)blockIdx.x * QSV_TPB + threadIdx.x;
   if (g >= ngroups) return;
   uint64_t base = ins_bits(g, ins);
-  if (swz) base = swz_5_11(base);                          // no target on bit 5 or 11 (host)
+  if (swz) base = swz_a_11(base, swz);                          // no target on bit 5 or 11 (host)
   cplx in[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) in[c] = NT ? ld_nt(amp + (base | offs.off[c])) : amp[base | offs.off[c]];

@@ -77,18 +77,22 @@ def test_controlled_1q_and_mcx_with_flags(lib, n):
         assert np.abs(e.amplitudes() - ref).max() < TOL
 
 
-@pytest.mark.parametrize("mask,nt", [(1, 0), (1, 1), (0, 0)])
-def test_controls_inside_a_cache_line_as_a_mask(lib, mask, nt):
+@pytest.mark.parametrize("mask,nt,swz", [(1, 0, 1), (1, 1, 2), (0, 0, 1), (1, 0, 2)])
+def test_controls_inside_a_cache_line_as_a_mask(lib, mask, nt, swz):
     """controlled X / 2x2 with controls on address bits 0..2: the masked full-line sweep (k_pair_m, default) and the
-    enumerating form, plain and non-temporal, targets below, between and above the controls, +-control values"""
+    enumerating form, plain and non-temporal, targets below, between and above the controls, +-control values; with the
+    index swizzle forced (2) the sixth free address bit changes places with bit 11 -- whichever bit that is when controls
+    or the target sit on bits 5..10, and not at all when bit 11 is taken"""
     n = 15
     rs = np.random.RandomState(5)
     ref = rand_state(n, 13)
     with lib.Engine(n) as e:
         e.set_option("lowctl_mask", mask)
         e.set_option("nontemporal", nt)
+        e.set_option("swizzle", swz)
         e.set_amplitudes(0, ref)
-        cases = [([1], 12), ([1, 5], 12), ([0, 2, 9], 4), ([2], 0), ([0, 1, 2], 14), ([1, 13], 2), ([2, 7, 11], 1), ([0], 1)]
+        cases = [([1], 12), ([1, 5], 12), ([0, 2, 9], 4), ([2], 0), ([0, 1, 2], 14), ([1, 13], 2), ([2, 7, 11], 1), ([0], 1),
+                 ([1, 5, 6], 7), ([2, 3, 4, 5], 8), ([0, 5], 11), ([1, 6, 8], 5)]
         for trial, (cs, t) in enumerate(cases * 2):
             vals = rs.randint(0, 2, size=len(cs)).tolist()
             if trial % 2:
@@ -300,8 +304,9 @@ def test_nontemporal_kernel_forms(lib):
 @pytest.mark.parametrize("swizzle", [2, 0])          # 2: also below 2^26 amplitudes, where 1 leaves it off
 def test_index_swizzle_of_the_one_gate_kernels(lib, swizzle):
     """The one-gate sweep kernels index their amplitudes with bits 5 and 11 exchanged (a wave access = two
-    512-byte runs 32 KiB apart) unless one of the two is a bit the gate singles out.  Gates
-    whose target / controls / selects sit on bits 5, 11 or next to them, both ways, against numpy."""
+    512-byte runs 32 KiB apart); a sweep that enumerates the indices with its controls and target left out
+    exchanges bit 11 with whichever address bit lane bit 5 lands on (the sixth free one), and leaves the swizzle out when
+    bit 11 is taken.  Gates whose target / controls / selects sit on bits 5, 11 or crowd the bits below, both ways, against numpy."""
     n = 16
     rs = np.random.RandomState(5 + swizzle)
     ref = rand_state(n, 43)
@@ -312,7 +317,8 @@ def test_index_swizzle_of_the_one_gate_kernels(lib, swizzle):
             m = rand_u(1, 900 + t)
             e.apply_1q(t, m)
             sv.apply_1q(ref, t, m)
-        for ctrls, t in (([5], 11), ([11], 5), ([5, 11], 3), ([3], 12), ([12, 4], 5), ([6], 11), ([10, 2], 14), ([], 5), ([], 11)):
+        for ctrls, t in (([5], 11), ([11], 5), ([5, 11], 3), ([3], 12), ([12, 4], 5), ([6], 11), ([10, 2], 14), ([], 5), ([], 11),
+                         ([3, 5, 6], 7), ([3, 4, 5, 6, 7], 9), ([0, 1, 2, 3, 4], 5), ([5, 6, 7, 8, 9], 10)):
             vals = [int(x) for x in rs.randint(0, 2, size=len(ctrls))]
             e.apply_mcx(ctrls, t, vals)
             sv.apply_mcx(ref, ctrls, t, vals)
