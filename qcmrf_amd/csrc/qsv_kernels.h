@@ -629,6 +629,25 @@ __global__ __launch_bounds__(QSV_TPB) void k_expect_diag(const cplx* __restrict_
   }
 }
 
+// second stage of a tiled reduction: (a, b) pairs, one per tile, summed in a fixed order into one pair per workgroup
+// (each workgroup a contiguous range of tiles, each thread a fixed stride through it, then wave and workgroup sums)
+__global__ __launch_bounds__(QSV_TPB) void k_reduce_pairs(const double* __restrict__ part, uint64_t npairs,
+                                                          double* __restrict__ out) {
+  const uint64_t per = (npairs + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < npairs ? lo + per : npairs;
+  double s0 = 0.0, s1 = 0.0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += QSV_TPB) { s0 += part[2 * i]; s1 += part[2 * i + 1]; }
+  __shared__ double red[2][QSV_TPB / 64];
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    out[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 #include "qsv_kmulti.h"
 
 // ---------------------------------------------------------------------------------------
