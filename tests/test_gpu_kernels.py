@@ -513,6 +513,37 @@ def test_expect_diag(lib, P):
         with pytest.raises(ValueError):
             e.expect_diag([1, 1], np.zeros(4))
 
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("variant", [6, 2])
+def test_expect_diag_tiled_and_grid_stride_walks(lib, P, variant):
+    """from 2^20 amplitudes per shard on, qsv_expect_diag runs one workgroup per 64 KiB tile and folds the tiles' partial
+    sums on the device in a fixed order (blocksum_variant & 4, the default); without the bit, a grid-stride walk: both
+    against numpy at 22 qubits, with and without a conditioning mask, narrow and wide tables, reproducibly"""
+    n = 22
+    ref = rand_state(n, 37)
+    p = np.abs(ref) ** 2
+    idx = np.arange(2 ** n)
+    rs = np.random.RandomState(11)
+    with lib.Engine(n, devices=(0,) * P) as e:
+        e.set_option("blocksum_variant", variant)
+        e.set_amplitudes(0, ref)
+        for k in (1, 7, 12, 14):
+            qs = [int(x) for x in rs.permutation(n)[:k]]
+            if k == 7:
+                qs[0] = n - 1                              # a shard bit (P = 2) among the table's qubits
+            tab = rs.randn(2 ** k)
+            j = np.zeros_like(idx)
+            for b, q in enumerate(qs):
+                j |= ((idx >> q) & 1) << b
+            got = e.expect_diag(qs, tab)
+            assert abs(got[0] - (p * tab[j]).sum()) < 1e-12 and abs(got[1] - 1.0) < 1e-12
+            assert e.expect_diag(qs, tab) == got
+            fm, fv = (1 << 21) | (1 << 4) | (1 << 13), (1 << 21) | (1 << 13)
+            sel = (idx & fm) == fv
+            got = e.expect_diag(qs, tab, fm, fv)
+            assert abs(got[0] - (p[sel] * tab[j[sel]]).sum()) < 1e-12 and abs(got[1] - p[sel].sum()) < 1e-12
+
+
 @pytest.mark.parametrize("n,P", [(10, 4), (11, 4), (9, 8), (7, 8), (11, 2)])
 def test_expect_diag_shards_smaller_than_one_step(lib, n, P):
     """shards of fewer than 1024 amplitudes (L < 10): qubits and fix bits on the shard bits in [L, 10) come from the
