@@ -20,7 +20,7 @@ if pmc:
 for name, qs in cases:
     u = ru(len(qs))
     line = "%-10s" % name
-    for variant, tile3, bpc, ch in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (3, 0, 0, 0), (4, 0, 0, 0), (5, 0, 0, 0), (8, 0, 0, 0), (3, 2, 0, 0)):
+    for variant, tile3, bpc, ch in ((3, 0, 0, 0), (6, 0, 0, 0), (6, 0, 64, 0), (7, 0, 0, 0), (7, 0, 64, 0), (8, 0, 0, 0), (8, 0, 16, 0), (8, 0, 64, 0), (3, 2, 0, 0)):
         if (tile3 and len(qs) != 3) or (pmc and (bpc or ch or variant in (0, 2))):
             continue
         eng.set_option("kq_variant", variant)
