@@ -244,6 +244,23 @@ def test_copy_state_has_read_the_source_before_the_source_moves_on(lib):
                 assert np.array_equal(g, w), rep
 
 
+@pytest.mark.parametrize("n,swz", [(12, 1), (16, 2)])
+def test_uncontrolled_x_on_every_target(lib, n, swz):
+    """X without controls: targets 0..4 go through the wave-shuffle sweep as the 2x2 they are, target 5 and up through
+    the pair sweep (with the swizzle forced: bit 6 in bit 5's place for target 5) -- every target, against numpy, exactly"""
+    ref = rand_state(n, 53)
+    with lib.Engine(n) as e:
+        e.set_option("swizzle", swz)
+        e.set_amplitudes(0, ref)
+        for t in list(range(n)) + [0, 5, 3]:
+            e.apply_mcx([], t)
+            sv.apply_mcx(ref, [], t, [])
+            m = rand_u(1, 300 + t)
+            e.apply_1q(t, m)
+            sv.apply_1q(ref, t, m)
+        assert np.abs(e.amplitudes() - ref).max() < 1e-13
+
+
 def test_measurement_knob_needs_the_opt_in(lib, monkeypatch):
     """kq_debug times the LDS-staged dense-gate kernel with a part of its work left out (scripts/kq_variants.py): the
     state it leaves is wrong by design, so the library takes it only with QSV_MEASUREMENT_KNOBS in the environment"""
