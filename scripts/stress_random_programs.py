@@ -64,6 +64,12 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
             elif k == 8:
                 kk = int(rs.randint(1, 4))
                 ops.append(ir.op_mcphase(qs[:kk], float(rs.randn()), vals=[int(v) for v in rs.randint(0, 2, size=kk)]))
+            elif rs.rand() < 0.4 and L >= 6:
+                # a dense 2..5-qubit gate on local qubits (every form of the matrix-core kernels is among the random options)
+                kk = int(rs.randint(2, min(5, L) + 1))
+                tq = [int(x) for x in rs.permutation(L)[:kk]]
+                u, _ = np.linalg.qr(rs.randn(2 ** kk, 2 ** kk) + 1j * rs.randn(2 ** kk, 2 ** kk))
+                ops.append(ir.op_kq(tq, u))
             else:
                 nc = int(rs.randint(0, 3))
                 ops.append(ir.op_u(qs[0], mat(), ctrls=qs[1:1 + nc], vals=[int(v) for v in rs.randint(0, 2, size=nc)]))
@@ -80,7 +86,9 @@ def run(n_cases=300, seed=7, verbose=True, only=None, override=None, widths=(14,
                 "init_prod_nt": int(rs.choice([-1, 1])), "pass_budget": int(rs.choice([0, 0, 30, 100])),
                 "general_r": int(rs.choice([4, 4, 5, 3, 2, 1])), "general_light_r": int(rs.choice([5, 5, 4, 3])),
                 "pass_max_ops": int(rs.choice([64, 64, 8, 200])), "swizzle": int(rs.choice([1, 2, 2, 0])),
-                "lane_map_min_l": int(rs.choice([26, 14, 14]))}
+                "lane_map_min_l": int(rs.choice([26, 14, 14])),
+                "kq_variant": int(rs.choice([-1, -1, 0, 3, 5, 6, 8])), "kq_order": int(rs.choice([1, 1, 0, 2, 4])),
+                "kq3_tile": int(rs.choice([1, 1, 0, 2]))}
         if only is not None and (case != only if only >= 0 else case < -only):
             continue                                       # replay mode (CASE, or -CASE: from that case on): the generator state advances, nothing runs
         if override:
