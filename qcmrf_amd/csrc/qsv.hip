@@ -185,9 +185,9 @@ struct qsv_handle {
   int opt_lowt_shuffle = 1;
   int opt_nt = -1;                    // one-gate sweeps non-temporal: -1 by shard size and bit positions (single_nt), 0 never, 1 always
   int opt_multi_r = 5;                // max distinct targets per k_multi pass (0: never group)
-  int opt_kq_variant = -1;            // k_kq_mfma: 0 four real products per complex one, 1 three (Gauss), 2 three + the next batch prefetched, 3 = 2 with the A fragments in LDS, 4 = 1 with them in LDS, 5 two batches per step 32 groups wide (lane swaps); -1 (default): 5 at K = 4, 3 at K = 5
+  int opt_kq_variant = -1;            // dense K = 4, 5 gates: 0 four real products per complex one, 1 three (Gauss), 2 three + next batch prefetched, 3 / 4 = 2 / 1 with the A fragments in LDS, 5 two batches per step 32 groups wide (lane swaps), 6 / 7 / 8 the batch staged through LDS with 1 / 2 / 3 batches of loads in flight; -1 (default): by K and placement (launch_kq_mfma)
   int opt_kq_order = 1;               // which target is index bit 0, 1, .. for the matrix-core kernels: 0 as given, 1 a target on address bit 11 first, 2 ascending, 3 descending, 4 nearest bit 11 first
-  int opt_kq_debug = 0;               // measurement only: the LDS-staged dense-gate kernel without products (1) / without memory traffic (2)
+  int opt_kq_debug = 0;               // measurement only (needs QSV_MEASUREMENT_KNOBS): the LDS-staged dense-gate kernel without products (1) / without memory traffic (2) / as a plain copy (3)
   int opt_lowctl_mask = 1;            // one-gate sweeps: controls on address bits 0..2 as a mask over whole lines (k_pair_m)
   int opt_general_combos = 1;         // general k_multi passes: controls on workgroup-uniform bits resolved per workgroup (combo table)
   int opt_fold_init_h = 1;            // qsv_exec: H on a still-|0> qubit right after an init is part of the init write
