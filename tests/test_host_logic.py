@@ -311,6 +311,11 @@ def test_trajectory_compile_live_width_and_segments():
     assert all(s.measure_slot == segs[0].measure_slot for s in segs[:-1])       # the same slot every time
     assert sorted(c for _, c in final) == [0, 1, 2, 3, 4, 5, 11]
     assert [s.n_ops for s in segs] == [2, 1, 1, 1, 1]         # init + mux, then one mux per clique
+    # every later segment carries, per outcome of the previous measurement, ONE record list: the 0/1 projection (and the X
+    # that hands the released slot back after outcome 1) in front of its own ops
+    assert segs[0].prog is None
+    for sg in segs[1:]:
+        assert len(sg.prog[0][0]) == sg.n_ops + 1 and len(sg.prog[1][0]) == sg.n_ops + 2
 
 
 @pytest.mark.parametrize("fusion", [0, 3])
